@@ -1,0 +1,200 @@
+/*
+ * relmc.h — C ABI of the MI355X-native non-sequential Monte Carlo HL2 engine.
+ *
+ * Drop-in boundary for the hot path of Matrixeigs/PowerSystemsReliabilityAssessment
+ * (SURVEY.md §8b).  The reference has no FFI of its own: its "operator API" is three
+ * MATLAB signatures, which the entry points below replace one for one:
+ *
+ *   relmc_case_load        <- loadcase + load model + failprob
+ *                             (Montecarlo_nsq_single/nsqMain.m:42,121-153,167; failprob.m:1-41)
+ *   relmc_mc_sampling      <- eqstatus = mc_sampling(U, n, Ng, Nl)          (mc_sampling.m:2)
+ *   relmc_mc_simulation    <- [dns, nodal_dns] = mc_simulation(state, ...)  (mc_simulation.m:1),
+ *                             batched over states (the parfor of nsqMain.m:257-263)
+ *   relmc_nsq_accumulate   <- one pass of the main loop body, fused sample -> evaluate -> reduce
+ *                             (nsqMain.m:212, 257-263, 269-278 folded into per-sample sums)
+ *   relmc_nsq_indices      <- the estimators of nsqMain.m:282-301, 348-349, 366-376
+ *   relmc_nsq_run          <- the whole `while beta > beta_limit` loop, nsqMain.m:208-318
+ *
+ * Conventions: plain C, no C++ or torch types; every buffer is owned by the caller and is
+ * not retained after the call returns; row-major arrays; all floating point is fp64;
+ * return value 0 = ok, <0 = relmc_status error (text via relmc_last_error); calls on one
+ * context are blocking and not re-entrant, distinct contexts are independent.  One context
+ * drives ONE GPU (one process per GPU; multi-GPU runs shard the global scenario index range
+ * and all-reduce relmc_acc).  There is NO CPU fallback: if no HIP device
+ * is usable every entry point fails with RELMC_ERR_NO_DEVICE.
+ */
+#ifndef RELMC_H
+#define RELMC_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define RELMC_MAX_BUS 128
+#define RELMC_MAX_COMP 256
+
+typedef enum {
+    RELMC_OK = 0,
+    RELMC_ERR_INVALID = -1,      /* bad argument */
+    RELMC_ERR_NO_DEVICE = -2,    /* no usable HIP device / HIP runtime error at create */
+    RELMC_ERR_HIP = -3,          /* HIP runtime error (see relmc_last_error) */
+    RELMC_ERR_UNSUPPORTED = -4,  /* case larger than the compiled kernel tiles */
+    RELMC_ERR_NO_CASE = -5       /* relmc_case_load has not been called */
+} relmc_status;
+
+/* How states that leave a bus with no in-service branch are evaluated. */
+typedef enum {
+    RELMC_REFERENCE_EMULATE = 0, /* MATPOWER/MIPS fails in iteration 1, the start point is
+                                    consumed unchecked (mc_simulation.m:41,54): dns = load/2 */
+    RELMC_PHYSICAL = 1           /* island-aware LP: every island gets its own angle reference */
+} relmc_singular_policy;
+
+/* Per-scenario solver status. */
+typedef enum {
+    RELMC_ST_CONVERGED = 0,
+    RELMC_ST_MAXIT = 1,          /* max_it reached (MIPS eflag 0)       */
+    RELMC_ST_NUMFAIL = 2,        /* MIPS "numerically failed" (eflag -1) */
+    RELMC_ST_SINGULAR = 3        /* isolated bus under RELMC_REFERENCE_EMULATE */
+} relmc_scenario_status;
+
+typedef struct relmc_ctx relmc_ctx;
+
+/* Study case = MATPOWER case after the load model of nsqMain.m:121-153, 0-based indices.
+ * Injections are the LP's generator columns in MATPOWER order: ng real generators then nd
+ * virtual generators (one per load bus: Pmax = 0, Pmin = -Pd, cost 1). */
+typedef struct {
+    double base_mva;
+    int32_t nb, ng, nl, nd;
+    int32_t ref_bus;
+    const double* bus_pd;     /* [nb]    MW, original bus loads                    */
+    const int32_t* inj_bus;   /* [ng+nd]                                           */
+    const double* inj_pmin;   /* [ng+nd] MW                                        */
+    const double* inj_pmax;   /* [ng+nd] MW                                        */
+    const double* inj_cost;   /* [ng+nd] linear cost c1 ($/MWh)                    */
+    const int32_t* br_from;   /* [nl]                                              */
+    const int32_t* br_to;     /* [nl]                                              */
+    const double* br_b;       /* [nl]    1/(x*tap) p.u. (makeBdc)                  */
+    const double* br_rate;    /* [nl]    MW, 0 = unconstrained                     */
+    const double* unavail;    /* [ng+nl] failure probabilities (failprob.m:39)     */
+    const uint8_t* always_up; /* [ng+nl] 1 = forced available (mc_sampling.m:40-41) */
+    double total_load;        /* TestSystem.load, nsqMain.m:125                    */
+} relmc_case_desc;
+
+/* MIPS options as MATPOWER sets them for OPF_ALG_DC=200 (nsqMain.m:185-186). */
+typedef struct {
+    int32_t singular_policy;  /* relmc_singular_policy */
+    int32_t max_it;           /* 150 */
+    double feastol;           /* 5e-6 (opf.violation) */
+    double gradtol;           /* 1e-6 */
+    double comptol;           /* 1e-6 */
+    double costtol;           /* 1e-6 */
+    double xi;                /* 0.99995 */
+    double sigma;             /* 0.1 */
+    double z0;                /* 1 */
+    double alpha_min;         /* 1e-8 */
+    double max_stepsize;      /* 1e10 */
+} relmc_solver_opts;
+
+/* Additive accumulators of one scenario range (what is all-reduced across GPUs). */
+typedef struct {
+    int64_t n;                /* scenarios evaluated                                  */
+    int64_t n_fail;           /* dns > 1e-4 (nsqMain.m:270)                            */
+    int64_t n_singular;       /* RELMC_ST_SINGULAR                                     */
+    int64_t n_infeasible;     /* states where an island needed Pmin relaxation / decommit */
+    int64_t n_nonconverged;   /* RELMC_ST_MAXIT or RELMC_ST_NUMFAIL                    */
+    int64_t sum_iters;        /* IPM iterations                                        */
+    int64_t comp_fail[RELMC_MAX_COMP]; /* sum over failed scenarios of state_k (nsqMain.m:373-376) */
+    double sum_dns;           /* sum dns      (nsqMain.m:286)                          */
+    double sum_dns2;          /* sum dns^2    (for beta, nsqMain.m:299-301)            */
+    double sum_nodal[RELMC_MAX_BUS];   /* sum nodal_dns (nsqMain.m:348)               */
+} relmc_acc;
+
+/* Reliability indices (nsqMain.m:282-301, 348-349, 366-376). */
+typedef struct {
+    int64_t n;
+    double edns;              /* MW                       */
+    double lole;              /* h/yr = plc*hours_per_year */
+    double plc;
+    double beta;              /* CoV of EDNS              */
+    double eens;              /* MWh/yr = edns*hours_per_year */
+    double mean_iters;
+    double nodal_eens[RELMC_MAX_BUS];        /* MW (the reference's nodal_eens; x8760 in its CSV) */
+    double comp_importance[RELMC_MAX_COMP];  /* P(component down | system failure) */
+} relmc_indices;
+
+typedef struct {
+    double beta_limit;        /* nsqMain.m:60  (0.0017) */
+    int64_t max_samples;      /* nsqMain.m:61  (1e5)    */
+    int64_t batch;            /* scenarios per convergence check (nsqMain.m:62 uses 100) */
+    uint64_t seed;
+    double hours_per_year;    /* 8760, nsqMain.m:292 */
+    relmc_solver_opts solver;
+    /* optional history buffers (may be NULL); capacity in checkpoints */
+    int64_t history_cap;
+    double* beta_history;
+    double* edns_history;
+    double* lole_history;
+    double* plc_history;
+} relmc_nsq_opts;
+
+typedef struct {
+    relmc_acc acc;
+    relmc_indices idx;
+    int64_t checkpoints;      /* history entries written */
+    int32_t converged;        /* beta <= beta_limit */
+    double wall_seconds;      /* host wall time of the loop */
+    double kernel_seconds;    /* HIP-event time of the fused kernels */
+} relmc_nsq_result;
+
+/* ---- lifetime ---------------------------------------------------------------------- */
+int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out);
+void relmc_ctx_destroy(relmc_ctx* ctx);
+const char* relmc_last_error(const relmc_ctx* ctx);
+const char* relmc_version(void);
+
+/* ---- setup ------------------------------------------------------------------------- */
+void relmc_solver_opts_default(relmc_solver_opts* opts);
+void relmc_nsq_opts_default(relmc_nsq_opts* opts);
+int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* desc);
+/* integer Bernoulli thresholds floor(U*2^32) the sampler compares against; out[ng+nl] */
+int32_t relmc_case_thresholds(const relmc_ctx* ctx, uint32_t* out);
+
+/* ---- mc_sampling (mc_sampling.m:2) -------------------------------------------------- */
+/* eqstatus[n x (ng+nl)] row-major, 1 = failed.  Deterministic in (seed, global index). */
+int32_t relmc_mc_sampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
+                          uint8_t* eqstatus_host);
+int32_t relmc_mc_sampling_dev(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
+                              uint8_t* eqstatus_dev);
+
+/* ---- mc_simulation (mc_simulation.m:1), batched ------------------------------------- */
+/* states[n x (ng+nl)]; dns[n]; nodal[n x nb]; status[n] / iters[n] may be NULL. */
+int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t n,
+                            const relmc_solver_opts* opts, double* dns_host, double* nodal_host,
+                            int32_t* status_host, int32_t* iters_host);
+/* same with every buffer already resident in this device's HBM */
+int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64_t n,
+                                const relmc_solver_opts* opts, double* dns_dev, double* nodal_dev,
+                                int32_t* status_dev, int32_t* iters_dev);
+
+/* ---- fused sample -> evaluate -> reduce (nsqMain.m:208-318 loop body) ---------------- */
+/* Evaluates global scenarios [first_index, first_index+n) and returns their accumulators. */
+int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
+                             const relmc_solver_opts* opts, relmc_acc* acc_out);
+/* HIP-event duration (ms) of the most recent fused / simulation kernel on the ctx stream */
+int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
+
+/* ---- estimators (host arithmetic, no device) ---------------------------------------- */
+void relmc_acc_zero(relmc_acc* acc);
+void relmc_acc_merge(relmc_acc* dst, const relmc_acc* src);
+void relmc_nsq_indices(const relmc_acc* acc, int32_t nb, int32_t ncomp, double hours_per_year,
+                       relmc_indices* out);
+
+/* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
+int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* RELMC_H */

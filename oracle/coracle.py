@@ -1,0 +1,107 @@
+"""TEST INFRASTRUCTURE ONLY — ctypes binding of oracle/librelmc_oracle.so (relmc_oracle.c).
+
+Importable only from tests/, tests/golden/make_*.py, __graft_entry__.smoke() and bench.py's
+cpu_baseline leg.  The product package never imports this module.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+import numpy as np
+
+from powersystemsreliabilityassessment_amd import _abi
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+_SO = os.path.join(_HERE, "librelmc_oracle.so")
+
+
+def build(force: bool = False) -> str:
+    src = os.path.join(_HERE, "relmc_oracle.c")
+    if force or not os.path.exists(_SO) or os.path.getmtime(_SO) < os.path.getmtime(src):
+        subprocess.check_call(["make", "-C", _HERE, "librelmc_oracle.so"], stdout=subprocess.DEVNULL)
+    return _SO
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is None:
+        build()
+        L = C.CDLL(_SO)
+        u8p, dp, i32p = _abi.c_uint8_p, _abi.c_double_p, _abi.c_int32_p
+        L.orc_mc_sampling.argtypes = [C.POINTER(_abi.CaseDesc), C.c_uint64, C.c_uint64, C.c_int64, u8p]
+        L.orc_mc_sampling.restype = C.c_int32
+        L.orc_mc_simulation.argtypes = [C.POINTER(_abi.CaseDesc), u8p, C.c_int64,
+                                        C.POINTER(_abi.SolverOpts), dp, dp, i32p, i32p, i32p, C.c_int32]
+        L.orc_mc_simulation.restype = C.c_int32
+        L.orc_nsq_accumulate.argtypes = [C.POINTER(_abi.CaseDesc), C.c_uint64, C.c_uint64, C.c_int64,
+                                         C.POINTER(_abi.SolverOpts), C.c_int32, C.c_int32,
+                                         C.POINTER(_abi.Acc)]
+        L.orc_nsq_accumulate.restype = C.c_int32
+        L.orc_nsq_indices.argtypes = [C.POINTER(_abi.Acc), C.c_int32, C.c_int32, C.c_double,
+                                      C.POINTER(_abi.Indices)]
+        L.orc_nsq_indices.restype = None
+        L.orc_thresholds.argtypes = [C.POINTER(_abi.CaseDesc), _abi.c_uint32_p]
+        L.orc_philox4x32_10.argtypes = [_abi.c_uint32_p, _abi.c_uint32_p, _abi.c_uint32_p]
+        L.orc_max_threads.restype = C.c_int32
+        _lib = L
+    return _lib
+
+
+class Oracle:
+    def __init__(self, case):
+        self.case = case
+        self.h = _abi.CaseHolder(case)
+        self.L = lib()
+
+    def thresholds(self):
+        out = np.zeros(self.case.ncomp, dtype=np.uint32)
+        self.L.orc_thresholds(C.byref(self.h.desc), out.ctypes.data_as(_abi.c_uint32_p))
+        return out
+
+    def mc_sampling(self, seed, first_index, n):
+        out = np.zeros((n, self.case.ncomp), dtype=np.uint8)
+        rc = self.L.orc_mc_sampling(C.byref(self.h.desc), seed, first_index, n,
+                                    out.ctypes.data_as(_abi.c_uint8_p))
+        assert rc == 0
+        return out
+
+    def mc_simulation(self, states, policy=_abi.RELMC_REFERENCE_EMULATE, opts=None, nthreads=1):
+        states = np.ascontiguousarray(states, dtype=np.uint8).reshape(-1, self.case.ncomp)
+        n = states.shape[0]
+        o = opts or _abi.default_solver_opts(policy)
+        dns = np.zeros(n)
+        nodal = np.zeros((n, self.case.nb))
+        status = np.zeros(n, dtype=np.int32)
+        iters = np.zeros(n, dtype=np.int32)
+        relaxed = np.zeros(n, dtype=np.int32)
+        rc = self.L.orc_mc_simulation(C.byref(self.h.desc), states.ctypes.data_as(_abi.c_uint8_p), n,
+                                      C.byref(o), dns.ctypes.data_as(_abi.c_double_p),
+                                      nodal.ctypes.data_as(_abi.c_double_p),
+                                      status.ctypes.data_as(_abi.c_int32_p),
+                                      iters.ctypes.data_as(_abi.c_int32_p),
+                                      relaxed.ctypes.data_as(_abi.c_int32_p), nthreads)
+        assert rc == 0
+        return dict(dns=dns, nodal=nodal, status=status, iters=iters, relaxed=relaxed)
+
+    def nsq_accumulate(self, seed, first_index, n, policy=_abi.RELMC_REFERENCE_EMULATE, opts=None,
+                       nthreads=None, memo=True):
+        o = opts or _abi.default_solver_opts(policy)
+        acc = _abi.Acc()
+        nt = nthreads or self.L.orc_max_threads()
+        rc = self.L.orc_nsq_accumulate(C.byref(self.h.desc), seed, first_index, n, C.byref(o), nt,
+                                       1 if memo else 0, C.byref(acc))
+        assert rc == 0
+        return acc
+
+    def indices(self, acc, hours=8760.0):
+        out = _abi.Indices()
+        self.L.orc_nsq_indices(C.byref(acc), self.case.nb, self.case.ncomp, hours, C.byref(out))
+        return out
+
+    def max_threads(self):
+        return int(self.L.orc_max_threads())

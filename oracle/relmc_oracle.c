@@ -1,0 +1,635 @@
+/*
+ * relmc_oracle.c — TEST INFRASTRUCTURE ONLY.  CPU restatement (plain C) of the reference's
+ * mc_sampling + mc_simulation hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
+ * cpu_baseline leg may load this library; the product (include/relmc.h) never does.
+ *
+ * PARITY UNPINNED per state: the arithmetic of the path lives in MATPOWER (runopf ->
+ * dcopf_solver -> qps_mips -> mips; call site Montecarlo_nsq_single/mc_simulation.m:41), an
+ * un-vendored and un-pinned dependency of the reference (README.md:46-48), and the reference
+ * holds no tests or per-state vectors.  This file restates MATPOWER's published algorithm
+ *  on the UNREDUCED formulation — variables [Va; Pg], MIPS' own
+ * equality/inequality split, the full (nx+neq) KKT system solved by LU with partial pivoting,
+ * as MATLAB's `\` would — so that it is independent of the reduced in-register elimination the
+ * HIP kernels use.  It is pinned (a) per state against scipy/HiGHS LP values and the numpy
+ * MIPS of oracle/pyoracle.py (tests/golden/states_fixture.json), (b) statistically against the
+ * reference's golden artifacts reliability_results.mat / nodal_results.csv
+ * (tests/golden/nsq_golden.json).
+ *
+ * Reference lines followed:
+ *   mc_sampling.m:24-41      -> orc_mc_sampling (counter-based RNG instead of rand, strict '<')
+ *   mc_simulation.m:32-37    -> status mapping (1 = failed -> component removed)
+ *   mc_simulation.m:41       -> solve_state (MATPOWER DC-OPF + MIPS)
+ *   mc_simulation.m:54-59    -> dns = f + load, dns < 0.1 -> 0
+ *   mc_simulation.m:62-99    -> nodal shed of the virtual generators, > 1e-3
+ *   nsqMain.m:270,282-301    -> accumulators (fail flag dns > 1e-4)
+ */
+#include "relmc_oracle.h"
+
+#include <math.h>
+#include <stdlib.h>
+#include <string.h>
+#ifdef _OPENMP
+#include <omp.h>
+#endif
+
+/* ------------------------------------------------------------------------------------ */
+/* Philox4x32-10 (Salmon, Moraes, Dror, Shaw: "Parallel random numbers: as easy as 1,2,3") */
+/* ------------------------------------------------------------------------------------ */
+static void philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    uint32_t c0 = ctr[0], c1 = ctr[1], c2 = ctr[2], c3 = ctr[3];
+    uint32_t k0 = key[0], k1 = key[1];
+    for (int r = 0; r < 10; ++r) {
+        uint64_t p0 = (uint64_t)0xD2511F53u * c0;
+        uint64_t p1 = (uint64_t)0xCD9E8D57u * c2;
+        uint32_t n0 = (uint32_t)(p1 >> 32) ^ c1 ^ k0;
+        uint32_t n1 = (uint32_t)p1;
+        uint32_t n2 = (uint32_t)(p0 >> 32) ^ c3 ^ k1;
+        uint32_t n3 = (uint32_t)p0;
+        c0 = n0; c1 = n1; c2 = n2; c3 = n3;
+        k0 += 0x9E3779B9u;
+        k1 += 0xBB67AE85u;
+    }
+    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
+}
+
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4])
+{
+    philox4x32_10(ctr, key, out);
+}
+
+void orc_thresholds(const relmc_case_desc* c, uint32_t* thr)
+{
+    int ncomp = c->ng + c->nl;
+    for (int k = 0; k < ncomp; ++k) {
+        double t = floor(c->unavail[k] * 4294967296.0);
+        if (t < 0) t = 0;
+        if (t > 4294967295.0) t = 4294967295.0;
+        thr[k] = c->always_up[k] ? 0u : (uint32_t)t;
+    }
+}
+
+/* one scenario: component k failed iff philox(ctr=(i_lo,i_hi,k>>2,0), key=seed)[k&3] < thr[k] */
+static void sample_state(const uint32_t* thr, int ncomp, uint64_t seed, uint64_t index, uint8_t* st)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int blk = 0; blk * 4 < ncomp; ++blk) {
+        uint32_t ctr[4] = {(uint32_t)index, (uint32_t)(index >> 32), (uint32_t)blk, 0u};
+        uint32_t r[4];
+        philox4x32_10(ctr, key, r);
+        for (int e = 0; e < 4 && blk * 4 + e < ncomp; ++e)
+            st[blk * 4 + e] = r[e] < thr[blk * 4 + e] ? 1 : 0;
+    }
+}
+
+int32_t orc_mc_sampling(const relmc_case_desc* c, uint64_t seed, uint64_t first_index, int64_t n,
+                        uint8_t* eqstatus)
+{
+    int ncomp = c->ng + c->nl;
+    uint32_t thr[RELMC_MAX_COMP];
+    if (ncomp > RELMC_MAX_COMP) return RELMC_ERR_UNSUPPORTED;
+    orc_thresholds(c, thr);
+    for (int64_t i = 0; i < n; ++i)
+        sample_state(thr, ncomp, seed, first_index + (uint64_t)i, eqstatus + i * ncomp);
+    return RELMC_OK;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* workspace                                                                            */
+/* ------------------------------------------------------------------------------------ */
+typedef struct {
+    int nx_max, neq_max, niq_max, nk_max;
+    /* sparse rows of Ae / Ai: each row has at most rw entries */
+    int rw;
+    int *ae_n, *ae_idx; double *ae_val, *be;
+    int *ai_n, *ai_idx; double *ai_val, *bi;
+    double *x, *x0, *c, *xmin, *xmax;
+    double *lam, *z, *mu, *h, *g, *Lx, *N, *dz, *dmu;
+    double *K, *rhs;
+    int *piv;
+    int *inj_of_col;     /* LP column -> case injection index */
+    int *lab, *deg;
+    uint8_t *inj_on, *br_on, *pin, *drop;
+    double *pmin;
+} orc_ws;
+
+static void* xm(size_t n) { void* p = calloc(n ? n : 1, 1); if (!p) abort(); return p; }
+
+static orc_ws* ws_new(const relmc_case_desc* c)
+{
+    orc_ws* w = (orc_ws*)xm(sizeof(orc_ws));
+    int ninj = c->ng + c->nd;
+    w->nx_max = c->nb + ninj;
+    w->neq_max = 2 * c->nb + ninj;            /* balance + pins + fixed injections */
+    w->niq_max = 2 * c->nl + 2 * ninj;
+    w->nk_max = w->nx_max + w->neq_max;
+    w->rw = c->nb + ninj + 1;
+    w->ae_n = xm(sizeof(int) * w->neq_max);
+    w->ae_idx = xm(sizeof(int) * (size_t)w->neq_max * w->rw);
+    w->ae_val = xm(sizeof(double) * (size_t)w->neq_max * w->rw);
+    w->be = xm(sizeof(double) * w->neq_max);
+    w->ai_n = xm(sizeof(int) * w->niq_max);
+    w->ai_idx = xm(sizeof(int) * (size_t)w->niq_max * 2);
+    w->ai_val = xm(sizeof(double) * (size_t)w->niq_max * 2);
+    w->bi = xm(sizeof(double) * w->niq_max);
+    w->x = xm(sizeof(double) * w->nx_max); w->x0 = xm(sizeof(double) * w->nx_max);
+    w->c = xm(sizeof(double) * w->nx_max);
+    w->xmin = xm(sizeof(double) * w->nx_max); w->xmax = xm(sizeof(double) * w->nx_max);
+    w->lam = xm(sizeof(double) * w->neq_max); w->g = xm(sizeof(double) * w->neq_max);
+    w->z = xm(sizeof(double) * w->niq_max); w->mu = xm(sizeof(double) * w->niq_max);
+    w->h = xm(sizeof(double) * w->niq_max); w->dz = xm(sizeof(double) * w->niq_max);
+    w->dmu = xm(sizeof(double) * w->niq_max);
+    w->Lx = xm(sizeof(double) * w->nx_max); w->N = xm(sizeof(double) * w->nx_max);
+    w->K = xm(sizeof(double) * (size_t)w->nk_max * w->nk_max);
+    w->rhs = xm(sizeof(double) * w->nk_max);
+    w->piv = xm(sizeof(int) * w->nk_max);
+    w->inj_of_col = xm(sizeof(int) * w->nx_max);
+    w->lab = xm(sizeof(int) * c->nb); w->deg = xm(sizeof(int) * c->nb);
+    w->inj_on = xm(ninj); w->br_on = xm(c->nl); w->pin = xm(c->nb); w->drop = xm(c->nb);
+    w->pmin = xm(sizeof(double) * ninj);
+    return w;
+}
+
+static void ws_free(orc_ws* w)
+{
+    free(w->ae_n); free(w->ae_idx); free(w->ae_val); free(w->be);
+    free(w->ai_n); free(w->ai_idx); free(w->ai_val); free(w->bi);
+    free(w->x); free(w->x0); free(w->c); free(w->xmin); free(w->xmax);
+    free(w->lam); free(w->g); free(w->z); free(w->mu); free(w->h); free(w->dz); free(w->dmu);
+    free(w->Lx); free(w->N); free(w->K); free(w->rhs); free(w->piv); free(w->inj_of_col);
+    free(w->lab); free(w->deg); free(w->inj_on); free(w->br_on); free(w->pin); free(w->drop);
+    free(w->pmin); free(w);
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* dense LU with partial pivoting (what MATLAB's `\` does for a square system)           */
+/* returns 0 ok, 1 exactly singular (zero pivot column -> Inf/NaN solution in MATLAB)    */
+/* ------------------------------------------------------------------------------------ */
+static int lu_solve(double* A, int n, int lda, double* b, int* piv)
+{
+    for (int k = 0; k < n; ++k) {
+        int p = k; double best = fabs(A[k * lda + k]);
+        for (int i = k + 1; i < n; ++i) {
+            double v = fabs(A[i * lda + k]);
+            if (v > best) { best = v; p = i; }
+        }
+        piv[k] = p;
+        if (best == 0.0 || best != best) return 1;
+        if (p != k) {
+            for (int j = 0; j < n; ++j) { double t = A[k * lda + j]; A[k * lda + j] = A[p * lda + j]; A[p * lda + j] = t; }
+            double t = b[k]; b[k] = b[p]; b[p] = t;
+        }
+        double inv = 1.0 / A[k * lda + k];
+        for (int i = k + 1; i < n; ++i) {
+            double m = A[i * lda + k];
+            if (m == 0.0) continue;
+            m *= inv;
+            A[i * lda + k] = m;
+            double* ri = A + i * lda; const double* rk = A + k * lda;
+            for (int j = k + 1; j < n; ++j) ri[j] -= m * rk[j];
+            b[i] -= m * b[k];
+        }
+    }
+    for (int i = n - 1; i >= 0; --i) {
+        double s = b[i];
+        const double* ri = A + i * lda;
+        for (int j = i + 1; j < n; ++j) s -= ri[j] * b[j];
+        b[i] = s / ri[i];
+    }
+    return 0;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* topology pre-processing (policy rows of SURVEY.md §8a)                                */
+/* ------------------------------------------------------------------------------------ */
+static int uf_find(int* p, int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]; } return a; }
+
+typedef struct { int singular; int n_relaxed; } pre_info;
+
+static pre_info preprocess(const relmc_case_desc* c, const uint8_t* st, int policy, orc_ws* w)
+{
+    pre_info pi = {0, 0};
+    int nb = c->nb, ng = c->ng, nl = c->nl, ninj = c->ng + c->nd;
+    for (int j = 0; j < ninj; ++j) { w->inj_on[j] = j < ng ? !st[j] : 1; w->pmin[j] = c->inj_pmin[j]; }
+    for (int i = 0; i < nb; ++i) { w->lab[i] = i; w->deg[i] = 0; w->pin[i] = 0; w->drop[i] = 0; }
+    for (int l = 0; l < nl; ++l) {
+        w->br_on[l] = !st[ng + l];
+        if (!w->br_on[l]) continue;
+        int f = c->br_from[l], t = c->br_to[l];
+        w->deg[f]++; w->deg[t]++;
+        int a = uf_find(w->lab, f), b = uf_find(w->lab, t);
+        if (a != b) { if (a < b) w->lab[b] = a; else w->lab[a] = b; }
+    }
+    for (int i = 0; i < nb; ++i) w->lab[i] = uf_find(w->lab, i);   /* label = lowest bus of island */
+    if (policy == RELMC_REFERENCE_EMULATE)
+        for (int i = 0; i < nb; ++i) if (w->deg[i] == 0) pi.singular = 1;
+    if (pi.singular) return pi;   /* never solved: MATPOWER's own start point is returned */
+    int ref_lab = w->lab[c->ref_bus];
+    for (int root = 0; root < nb; ++root) {
+        if (w->lab[root] != root) continue;
+        int pin = root == ref_lab ? c->ref_bus : root;
+        w->pin[pin] = 1;
+        int n_inj = 0, n_load = 0, n_gen = 0, n_free = 0; double lo_sum = 0;
+#define IN_ISLAND(j) (w->inj_on[j] && w->lab[c->inj_bus[j]] == root)
+        for (int j = 0; j < ninj; ++j)
+            if (IN_ISLAND(j)) {
+                n_inj++; lo_sum += c->inj_pmin[j];
+                if (j >= ng) n_load++; else if (c->inj_pmax[j] > 0) n_gen++;
+            }
+        if (n_inj && !n_load) {          /* rule 2: island without load: decommit its generators */
+            for (int j = 0; j < ng; ++j) if (IN_ISLAND(j)) w->inj_on[j] = 0;
+            pi.n_relaxed++;
+        } else if (n_load && !n_gen) {   /* rule 3: island without generation: all load shed, p = 0 */
+            for (int j = ng; j < ninj; ++j) if (IN_ISLAND(j)) w->pmin[j] = 0.0;
+        } else if (lo_sum > 1e-9) {      /* rule 4: over-generation: relax Pmin of the island's units */
+            for (int j = 0; j < ng; ++j) if (IN_ISLAND(j)) w->pmin[j] = 0.0;
+            pi.n_relaxed++;
+        }
+        for (int j = 0; j < ninj; ++j) if (IN_ISLAND(j) && c->inj_pmax[j] - w->pmin[j] > 0) n_free++;
+        if (!n_free) w->drop[pin] = 1;   /* rule 5: balance rows of the island are dependent */
+#undef IN_ISLAND
+    }
+    return pi;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* one state: MATPOWER DC-OPF assembly + MIPS                                            */
+/* ------------------------------------------------------------------------------------ */
+static void add_ae(orc_ws* w, int row, int idx, double val)
+{
+    int n = w->ae_n[row]++;
+    w->ae_idx[row * w->rw + n] = idx; w->ae_val[row * w->rw + n] = val;
+}
+
+static void finish(const relmc_case_desc* c, const orc_ws* w, int ncol, double f, double* dns_out,
+                   double* nodal)
+{
+    /* mc_simulation.m:54-59 */
+    double dns = f + c->total_load;
+    if (dns < 0.1) dns = 0.0;
+    for (int i = 0; i < c->nb; ++i) nodal[i] = 0.0;
+    if (dns > 0) {                       /* mc_simulation.m:65 */
+        for (int col = 0; col < ncol; ++col) {
+            int j = w->inj_of_col[col];
+            if (j < c->ng) continue;
+            double shed = w->x[c->nb + col] * c->base_mva - c->inj_pmin[j];   /* Pg - Pmin, :86 */
+            if (shed > 1e-3) nodal[c->inj_bus[j]] = shed;                      /* :90-97 */
+        }
+    }
+    *dns_out = dns;
+}
+
+static void solve_state(const relmc_case_desc* c, const uint8_t* st, const relmc_solver_opts* o,
+                        orc_ws* w, double* dns, double* nodal, int32_t* status, int32_t* iters,
+                        int32_t* relaxed)
+{
+    const int nb = c->nb, nl = c->nl, ninj = c->ng + c->nd;
+    const double base = c->base_mva;
+    const double eps = 2.220446049250313e-16;
+    pre_info pi = preprocess(c, st, o->singular_policy, w);
+    *relaxed = pi.n_relaxed;
+
+    /* ---- variables: x = [Va(nb); Pg of in-service injections] (ext2int drops the rest) */
+    int ncol = 0;
+    for (int j = 0; j < ninj; ++j) if (w->inj_on[j]) w->inj_of_col[ncol++] = j;
+    const int nx = nb + ncol;
+    for (int i = 0; i < nb; ++i) {
+        w->c[i] = 0.0;
+        if (w->pin[i]) { w->xmin[i] = 0.0; w->xmax[i] = 0.0; }
+        else { w->xmin[i] = -INFINITY; w->xmax[i] = INFINITY; }
+    }
+    for (int col = 0; col < ncol; ++col) {
+        int j = w->inj_of_col[col];
+        w->xmin[nb + col] = w->pmin[j] / base;
+        w->xmax[nb + col] = c->inj_pmax[j] / base;
+        w->c[nb + col] = c->inj_cost[j] * base;        /* opf_setup: c1 * baseMVA */
+    }
+    /* dcopf_solver start: midpoint of bounds (Inf -> +-1e10), all angles = ref angle */
+    for (int k = 0; k < nx; ++k) {
+        double lb = isinf(w->xmin[k]) ? -1e10 : w->xmin[k];
+        double ub = isinf(w->xmax[k]) ? 1e10 : w->xmax[k];
+        w->x0[k] = k < nb ? 0.0 : (lb + ub) / 2.0;
+    }
+    if (pi.singular) {
+        /* isolated bus: zero KKT column -> MATLAB `\` returns Inf/NaN -> mips breaks in
+         * iteration 1 ("numerically failed") and returns x0 */
+        double f = 0;
+        for (int k = 0; k < nx; ++k) { w->x[k] = w->x0[k]; f += w->c[k] * w->x0[k]; }
+        finish(c, w, ncol, f, dns, nodal);
+        *status = RELMC_ST_SINGULAR; *iters = 0;
+        return;
+    }
+
+    /* ---- mips: AA = [I; A], split into equalities / inequalities --------------------- */
+    int neq = 0, niq = 0;
+    /* variable-bound rows first (AA = [speye(nx); A]) — classified like mips.m:         */
+    /* ieq: |uu-ll|<=eps ; ilt: ll<=-1e10 & uu<1e10 ; igt: uu>=1e10 & ll>-1e10 ; ibx      */
+    /* Ai = [AA(ilt); -AA(igt); AA(ibx); -AA(ibx)], built in four passes to keep the order */
+    /* equalities */
+    for (int k = 0; k < nx; ++k)
+        if (fabs(w->xmax[k] - w->xmin[k]) <= eps) { w->ae_n[neq] = 0; add_ae(w, neq, k, 1.0); w->be[neq] = w->xmax[k]; neq++; }
+    for (int i = 0; i < nb; ++i) {                  /* Pmis rows: Bbus*Va - Cg*Pg = 0 */
+        if (w->drop[i]) continue;
+        w->ae_n[neq] = 0;
+        /* Bbus row i = sum over in-service branches at i (makeBdc) */
+        double diag = 0;
+        for (int l = 0; l < nl; ++l) {
+            if (!w->br_on[l]) continue;
+            if (c->br_from[l] == i) { diag += c->br_b[l]; add_ae(w, neq, c->br_to[l], -c->br_b[l]); }
+            else if (c->br_to[l] == i) { diag += c->br_b[l]; add_ae(w, neq, c->br_from[l], -c->br_b[l]); }
+        }
+        if (diag != 0) add_ae(w, neq, i, diag);
+        for (int col = 0; col < ncol; ++col)
+            if (c->inj_bus[w->inj_of_col[col]] == i) add_ae(w, neq, nb + col, -1.0);
+        w->be[neq] = 0.0;
+        neq++;
+    }
+#define ADD_AI(i0, v0, i1, v1, rhs)                                                      \
+    do { w->ai_idx[niq * 2] = (i0); w->ai_val[niq * 2] = (v0); w->ai_idx[niq * 2 + 1] = (i1); \
+         w->ai_val[niq * 2 + 1] = (v1); w->ai_n[niq] = ((i1) >= 0) ? 2 : 1; w->bi[niq] = (rhs); niq++; } while (0)
+    /* pass ilt / igt on variable bounds: none of our variables is one-sided (angles are
+     * free or pinned, injections are boxed or fixed); keep the general test anyway */
+    for (int k = 0; k < nx; ++k)
+        if (w->xmin[k] <= -1e10 && w->xmax[k] < 1e10) ADD_AI(k, 1.0, -1, 0.0, w->xmax[k]);
+    for (int k = 0; k < nx; ++k)
+        if (w->xmax[k] >= 1e10 && w->xmin[k] > -1e10) ADD_AI(k, -1.0, -1, 0.0, -w->xmin[k]);
+    /* ibx upper: variable boxes, then the two-sided flow rows -rate <= Bf*Va <= rate */
+    for (int k = 0; k < nx; ++k)
+        if (fabs(w->xmax[k] - w->xmin[k]) > eps && w->xmax[k] < 1e10 && w->xmin[k] > -1e10)
+            ADD_AI(k, 1.0, -1, 0.0, w->xmax[k]);
+    for (int l = 0; l < nl; ++l)
+        if (w->br_on[l] && c->br_rate[l] != 0)
+            ADD_AI(c->br_from[l], c->br_b[l], c->br_to[l], -c->br_b[l], c->br_rate[l] / base);
+    /* ibx lower */
+    for (int k = 0; k < nx; ++k)
+        if (fabs(w->xmax[k] - w->xmin[k]) > eps && w->xmax[k] < 1e10 && w->xmin[k] > -1e10)
+            ADD_AI(k, -1.0, -1, 0.0, -w->xmin[k]);
+    for (int l = 0; l < nl; ++l)
+        if (w->br_on[l] && c->br_rate[l] != 0)
+            ADD_AI(c->br_from[l], -c->br_b[l], c->br_to[l], c->br_b[l], c->br_rate[l] / base);
+#undef ADD_AI
+
+    /* ---- initialise (mips.m) ------------------------------------------------------- */
+    double* x = w->x;
+    double f = 0;
+    for (int k = 0; k < nx; ++k) { x[k] = w->x0[k]; f += w->c[k] * x[k]; }
+#define EVAL_H()                                                                          \
+    for (int r = 0; r < niq; ++r) {                                                       \
+        double s = w->ai_val[r * 2] * x[w->ai_idx[r * 2]];                               \
+        if (w->ai_n[r] == 2) s += w->ai_val[r * 2 + 1] * x[w->ai_idx[r * 2 + 1]];         \
+        w->h[r] = s - w->bi[r];                                                           \
+    }
+#define EVAL_G()                                                                          \
+    for (int r = 0; r < neq; ++r) {                                                       \
+        double s = 0;                                                                     \
+        for (int e = 0; e < w->ae_n[r]; ++e) s += w->ae_val[r * w->rw + e] * x[w->ae_idx[r * w->rw + e]]; \
+        w->g[r] = s - w->be[r];                                                           \
+    }
+#define EVAL_LX()                                                                         \
+    for (int k = 0; k < nx; ++k) w->Lx[k] = w->c[k];                                      \
+    for (int r = 0; r < neq; ++r)                                                         \
+        for (int e = 0; e < w->ae_n[r]; ++e) w->Lx[w->ae_idx[r * w->rw + e]] += w->ae_val[r * w->rw + e] * w->lam[r]; \
+    for (int r = 0; r < niq; ++r)                                                         \
+        for (int e = 0; e < w->ai_n[r]; ++e) w->Lx[w->ai_idx[r * 2 + e]] += w->ai_val[r * 2 + e] * w->mu[r];
+    EVAL_H(); EVAL_G();
+    double gamma = 1.0;
+    for (int r = 0; r < neq; ++r) w->lam[r] = 0.0;
+    for (int r = 0; r < niq; ++r) {
+        w->z[r] = o->z0; w->mu[r] = o->z0;
+        if (w->h[r] < -o->z0) w->z[r] = -w->h[r];
+        if (gamma / w->z[r] > o->z0) w->mu[r] = gamma / w->z[r];
+    }
+    double f0 = f;
+    EVAL_LX();
+    int converged = 0, eflag = 0, it = 0;
+    /* (the pre-loop convergence test of mips.m can never pass: compcond = niq/(1+|x|) >> tol) */
+    const int nk = nx + neq;
+    while (!converged && it < o->max_it) {
+        it++;
+        /* M = Ai' diag(mu./z) Ai ; N = Lx + Ai' ((mu.*h + gamma)./z) */
+        for (int i = 0; i < nk * nk; ++i) w->K[i] = 0.0;
+        for (int k = 0; k < nx; ++k) w->N[k] = w->Lx[k];
+        for (int r = 0; r < niq; ++r) {
+            double zinv = 1.0 / w->z[r];
+            double d = w->mu[r] * zinv;
+            double t = (w->mu[r] * w->h[r] + gamma) * zinv;
+            for (int a = 0; a < w->ai_n[r]; ++a) {
+                int ia = w->ai_idx[r * 2 + a]; double va = w->ai_val[r * 2 + a];
+                w->N[ia] += va * t;
+                for (int b = 0; b < w->ai_n[r]; ++b)
+                    w->K[ia * nk + w->ai_idx[r * 2 + b]] += va * d * w->ai_val[r * 2 + b];
+            }
+        }
+        for (int r = 0; r < neq; ++r)
+            for (int e = 0; e < w->ae_n[r]; ++e) {
+                int k = w->ae_idx[r * w->rw + e]; double v = w->ae_val[r * w->rw + e];
+                w->K[k * nk + nx + r] += v; w->K[(nx + r) * nk + k] += v;   /* parallel lines repeat (row, col) */
+            }
+        for (int k = 0; k < nx; ++k) w->rhs[k] = -w->N[k];
+        for (int r = 0; r < neq; ++r) w->rhs[nx + r] = -w->g[r];
+        int sing = lu_solve(w->K, nk, nk, w->rhs, w->piv);
+        double nrm = 0; int bad = sing;
+        for (int k = 0; k < nk && !bad; ++k) { if (w->rhs[k] != w->rhs[k]) bad = 1; nrm += w->rhs[k] * w->rhs[k]; }
+        if (bad || sqrt(nrm) > o->max_stepsize) { eflag = -1; break; }
+        const double* dx = w->rhs; const double* dlam = w->rhs + nx;
+        double alphap = 1.0, alphad = 1.0, minp = INFINITY, mind = INFINITY;
+        for (int r = 0; r < niq; ++r) {
+            double s = w->ai_val[r * 2] * dx[w->ai_idx[r * 2]];
+            if (w->ai_n[r] == 2) s += w->ai_val[r * 2 + 1] * dx[w->ai_idx[r * 2 + 1]];
+            w->dz[r] = -w->h[r] - w->z[r] - s;
+            w->dmu[r] = -w->mu[r] + (gamma - w->mu[r] * w->dz[r]) / w->z[r];
+            if (w->dz[r] < 0) { double q = w->z[r] / -w->dz[r]; if (q < minp) minp = q; }
+            if (w->dmu[r] < 0) { double q = w->mu[r] / -w->dmu[r]; if (q < mind) mind = q; }
+        }
+        if (minp < INFINITY) { alphap = o->xi * minp; if (alphap > 1.0) alphap = 1.0; }
+        if (mind < INFINITY) { alphad = o->xi * mind; if (alphad > 1.0) alphad = 1.0; }
+        for (int k = 0; k < nx; ++k) x[k] += alphap * dx[k];
+        double zmu = 0;
+        for (int r = 0; r < niq; ++r) { w->z[r] += alphap * w->dz[r]; w->mu[r] += alphad * w->dmu[r]; zmu += w->z[r] * w->mu[r]; }
+        for (int r = 0; r < neq; ++r) w->lam[r] += alphad * dlam[r];
+        if (niq > 0) gamma = o->sigma * zmu / niq;
+        f = 0; for (int k = 0; k < nx; ++k) f += w->c[k] * x[k];
+        EVAL_H(); EVAL_G(); EVAL_LX();
+        double gmax = 0, hmax = -INFINITY, xmaxn = 0, zmaxn = 0, lxmax = 0, lammax = 0, mumax = 0;
+        int xnan = 0;
+        for (int r = 0; r < neq; ++r) { if (fabs(w->g[r]) > gmax) gmax = fabs(w->g[r]); if (fabs(w->lam[r]) > lammax) lammax = fabs(w->lam[r]); }
+        for (int r = 0; r < niq; ++r) { if (w->h[r] > hmax) hmax = w->h[r]; if (fabs(w->z[r]) > zmaxn) zmaxn = fabs(w->z[r]); if (fabs(w->mu[r]) > mumax) mumax = fabs(w->mu[r]); }
+        for (int k = 0; k < nx; ++k) { if (fabs(x[k]) > xmaxn) xmaxn = fabs(x[k]); if (fabs(w->Lx[k]) > lxmax) lxmax = fabs(w->Lx[k]); if (x[k] != x[k]) xnan = 1; }
+        double feascond = (gmax > hmax ? gmax : hmax) / (1 + (xmaxn > zmaxn ? xmaxn : zmaxn));
+        double gradcond = lxmax / (1 + (lammax > mumax ? lammax : mumax));
+        double compcond = zmu / (1 + xmaxn);
+        double costcond = fabs(f - f0) / (1 + fabs(f0));
+        if (feascond < o->feastol && gradcond < o->gradtol && compcond < o->comptol && costcond < o->costtol) {
+            converged = 1;
+        } else {
+            if (xnan || alphap < o->alpha_min || alphad < o->alpha_min || gamma < eps || gamma > 1 / eps) { eflag = -1; break; }
+            f0 = f;
+        }
+    }
+#undef EVAL_H
+#undef EVAL_G
+#undef EVAL_LX
+    finish(c, w, ncol, f, dns, nodal);
+    *status = converged ? RELMC_ST_CONVERGED : (eflag == -1 ? RELMC_ST_NUMFAIL : RELMC_ST_MAXIT);
+    *iters = it;
+}
+
+/* ------------------------------------------------------------------------------------ */
+/* public oracle entry points                                                            */
+/* ------------------------------------------------------------------------------------ */
+int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64_t n,
+                          const relmc_solver_opts* opts, double* dns, double* nodal,
+                          int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads)
+{
+    int ncomp = c->ng + c->nl;
+    if (c->nb > RELMC_MAX_BUS || ncomp > RELMC_MAX_COMP) return RELMC_ERR_UNSUPPORTED;
+    if (nthreads < 1) nthreads = 1;
+#pragma omp parallel num_threads(nthreads)
+    {
+        orc_ws* w = ws_new(c);
+        double nd[RELMC_MAX_BUS];
+#pragma omp for schedule(dynamic, 16)
+        for (int64_t i = 0; i < n; ++i) {
+            double d; int32_t s, it, rx;
+            solve_state(c, states + i * ncomp, opts, w, &d, nd, &s, &it, &rx);
+            dns[i] = d;
+            if (nodal) memcpy(nodal + i * c->nb, nd, sizeof(double) * c->nb);
+            if (status) status[i] = s;
+            if (iters) iters[i] = it;
+            if (relaxed) relaxed[i] = rx;
+        }
+        ws_free(w);
+    }
+    return RELMC_OK;
+}
+
+/* memo cache (test speed-up only; the reference's own state_database, nsqMain.m:220-245) */
+typedef struct { uint64_t k[4]; double dns; int32_t status, iters, relaxed; int used; double nodal[RELMC_MAX_BUS]; } memo_ent;
+typedef struct { memo_ent* e; size_t cap, n; } memo_t;
+
+static uint64_t mix64(uint64_t x) { x ^= x >> 33; x *= 0xff51afd7ed558ccdULL; x ^= x >> 33; x *= 0xc4ceb9fe1a85ec53ULL; x ^= x >> 33; return x; }
+
+static memo_ent* memo_find(memo_t* m, const uint64_t k[4])
+{
+    if (m->n * 2 >= m->cap) {
+        size_t ncap = m->cap ? m->cap * 2 : 1024;
+        memo_ent* ne = (memo_ent*)xm(sizeof(memo_ent) * ncap);
+        for (size_t i = 0; i < m->cap; ++i) if (m->e[i].used) {
+            size_t p = mix64(m->e[i].k[0] ^ mix64(m->e[i].k[1] ^ mix64(m->e[i].k[2] ^ mix64(m->e[i].k[3])))) & (ncap - 1);
+            while (ne[p].used) p = (p + 1) & (ncap - 1);
+            ne[p] = m->e[i];
+        }
+        free(m->e); m->e = ne; m->cap = ncap;
+    }
+    size_t p = mix64(k[0] ^ mix64(k[1] ^ mix64(k[2] ^ mix64(k[3])))) & (m->cap - 1);
+    while (m->e[p].used) {
+        if (m->e[p].k[0] == k[0] && m->e[p].k[1] == k[1] && m->e[p].k[2] == k[2] && m->e[p].k[3] == k[3]) return &m->e[p];
+        p = (p + 1) & (m->cap - 1);
+    }
+    memcpy(m->e[p].k, k, sizeof(uint64_t) * 4);
+    return &m->e[p];
+}
+
+static void acc_add(relmc_acc* a, const relmc_case_desc* c, const uint8_t* st, double dns,
+                    const double* nodal, int32_t status, int32_t iters, int32_t relaxed)
+{
+    int ncomp = c->ng + c->nl;
+    a->n += 1;
+    a->sum_dns += dns;
+    a->sum_dns2 += dns * dns;
+    a->sum_iters += iters;
+    if (status == RELMC_ST_SINGULAR) a->n_singular += 1;
+    if (status == RELMC_ST_MAXIT || status == RELMC_ST_NUMFAIL) a->n_nonconverged += 1;
+    if (relaxed) a->n_infeasible += 1;
+    for (int i = 0; i < c->nb; ++i) a->sum_nodal[i] += nodal[i];
+    if (dns > 1e-4) {                                    /* nsqMain.m:270 */
+        a->n_fail += 1;
+        for (int k = 0; k < ncomp; ++k) a->comp_fail[k] += st[k];
+    }
+}
+
+static void acc_merge(relmc_acc* d, const relmc_acc* s)
+{
+    d->n += s->n; d->n_fail += s->n_fail; d->n_singular += s->n_singular;
+    d->n_infeasible += s->n_infeasible; d->n_nonconverged += s->n_nonconverged;
+    d->sum_iters += s->sum_iters; d->sum_dns += s->sum_dns; d->sum_dns2 += s->sum_dns2;
+    for (int k = 0; k < RELMC_MAX_COMP; ++k) d->comp_fail[k] += s->comp_fail[k];
+    for (int i = 0; i < RELMC_MAX_BUS; ++i) d->sum_nodal[i] += s->sum_nodal[i];
+}
+
+int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t first_index, int64_t n,
+                           const relmc_solver_opts* opts, int32_t nthreads, int32_t use_memo,
+                           relmc_acc* acc_out)
+{
+    int ncomp = c->ng + c->nl;
+    if (c->nb > RELMC_MAX_BUS || ncomp > RELMC_MAX_COMP) return RELMC_ERR_UNSUPPORTED;
+    if (nthreads < 1) nthreads = 1;
+    uint32_t thr[RELMC_MAX_COMP];
+    orc_thresholds(c, thr);
+    relmc_acc* part = (relmc_acc*)xm(sizeof(relmc_acc) * nthreads);
+#pragma omp parallel num_threads(nthreads)
+    {
+#ifdef _OPENMP
+        int tid = omp_get_thread_num();
+#else
+        int tid = 0;
+#endif
+        orc_ws* w = ws_new(c);
+        memo_t memo = {0, 0, 0};
+        uint8_t st[RELMC_MAX_COMP];
+        double nd[RELMC_MAX_BUS];
+        /* contiguous chunk per thread, merged in thread order: deterministic sums */
+        int64_t lo = n * tid / nthreads, hi = n * (tid + 1) / nthreads;
+        for (int64_t i = lo; i < hi; ++i) {
+            double d; int32_t s, it, rx;
+            sample_state(thr, ncomp, seed, first_index + (uint64_t)i, st);
+            if (use_memo && ncomp <= 256) {
+                uint64_t key[4] = {0, 0, 0, 0};
+                for (int k = 0; k < ncomp; ++k) if (st[k]) key[k >> 6] |= 1ULL << (k & 63);
+                memo_ent* e = memo_find(&memo, key);
+                if (!e->used) {
+                    solve_state(c, st, opts, w, &e->dns, e->nodal, &e->status, &e->iters, &e->relaxed);
+                    e->used = 1; memo.n++;
+                }
+                acc_add(&part[tid], c, st, e->dns, e->nodal, e->status, e->iters, e->relaxed);
+            } else {
+                solve_state(c, st, opts, w, &d, nd, &s, &it, &rx);
+                acc_add(&part[tid], c, st, d, nd, s, it, rx);
+            }
+        }
+        free(memo.e);
+        ws_free(w);
+    }
+    memset(acc_out, 0, sizeof(*acc_out));
+    for (int t = 0; t < nthreads; ++t) acc_merge(acc_out, &part[t]);
+    free(part);
+    return RELMC_OK;
+}
+
+/* estimators, nsqMain.m:282-301, 348-349, 366-376 (independent restatement of relmc_nsq_indices) */
+void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out)
+{
+    memset(out, 0, sizeof(*out));
+    out->n = a->n;
+    if (a->n <= 0) return;
+    double N = (double)a->n;
+    out->edns = a->sum_dns / N;
+    out->plc = (double)a->n_fail / N;
+    out->lole = out->plc * hours;
+    out->eens = out->edns * hours;
+    double ss = a->sum_dns2 - N * out->edns * out->edns;     /* sum (dns - EDNS)^2 */
+    if (ss < 0) ss = 0;
+    out->beta = out->edns > 0 ? sqrt(ss) / N / out->edns : INFINITY;
+    out->mean_iters = (double)a->sum_iters / N;
+    for (int i = 0; i < nb; ++i) out->nodal_eens[i] = a->sum_nodal[i] / N;
+    for (int k = 0; k < ncomp; ++k) out->comp_importance[k] = a->n_fail ? (double)a->comp_fail[k] / (double)a->n_fail : 0.0;
+}
+
+int32_t orc_max_threads(void)
+{
+#ifdef _OPENMP
+    return omp_get_max_threads();
+#else
+    return 1;
+#endif
+}

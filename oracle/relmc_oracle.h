@@ -1,0 +1,26 @@
+/*
+ * relmc_oracle.h — TEST INFRASTRUCTURE ONLY (see relmc_oracle.c).  CPU restatement of the
+ * reference hot path; shares only the plain-data structs of include/relmc.h.
+ */
+#ifndef RELMC_ORACLE_H
+#define RELMC_ORACLE_H
+#include "../include/relmc.h"
+#ifdef __cplusplus
+extern "C" {
+#endif
+void orc_philox4x32_10(const uint32_t ctr[4], const uint32_t key[2], uint32_t out[4]);
+void orc_thresholds(const relmc_case_desc* c, uint32_t* thr);
+int32_t orc_mc_sampling(const relmc_case_desc* c, uint64_t seed, uint64_t first_index, int64_t n,
+                        uint8_t* eqstatus);
+int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64_t n,
+                          const relmc_solver_opts* opts, double* dns, double* nodal,
+                          int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads);
+int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t first_index, int64_t n,
+                           const relmc_solver_opts* opts, int32_t nthreads, int32_t use_memo,
+                           relmc_acc* acc_out);
+void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out);
+int32_t orc_max_threads(void);
+#ifdef __cplusplus
+}
+#endif
+#endif

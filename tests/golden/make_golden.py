@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""Generates the committed golden fixtures (run in the build container only).
+
+  python tests/golden/make_golden.py [--reference /root/reference]
+
+Outputs (all small JSON, data only):
+  nsq_golden.json       the reference's own golden NSQ artifacts
+                        (Montecarlo_nsq_single/reliability_results.mat + nodal_results.csv,
+                        written by nsqMain.m:398-405), converted with scipy.io.loadmat.
+  states_fixture.json   a fixed list of component states with, per state and policy,
+                        the scipy/HiGHS LP value (unique optimum -> pins total dns) and the
+                        numpy MIPS restatement's dns / nodal / iterations / status
+                        (oracle/pyoracle.py).
+  nsq_seed1_1e5.json    the estimator outputs (EDNS, LOLE, PLC, beta, nodal EENS, component
+                        importance; nsqMain.m:282-301,348-349,366-376) for seed 1, N = 1e5,
+                        computed in Python exactly as the reference does it: unique-state
+                        database with occurrence counts (nsqMain.m:220-245,269-301).
+
+Nothing here is read at test time from /root/reference; the JSON files are.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import multiprocessing as mp
+import os
+import sys
+
+import numpy as np
+
+HERE = os.path.dirname(os.path.abspath(__file__))
+ROOT = os.path.dirname(os.path.dirname(HERE))
+sys.path.insert(0, ROOT)
+
+from powersystemsreliabilityassessment_amd import case24  # noqa: E402
+from oracle import pyoracle as po  # noqa: E402
+
+CASE = case24.rts24()
+
+
+def _eval(args):
+    idx_list, policy = args
+    st = np.zeros(CASE.ncomp, dtype=np.uint8)
+    st[list(idx_list)] = 1
+    m = po.mips_full(CASE, st, policy)
+    h = po.lp_highs(CASE, st, policy)
+    return dict(dns=float(m["dns"]), nodal=[float(v) for v in m["nodal"]], iters=int(m["iters"]),
+                status=int(m["status"]), relaxed=int(m["n_relaxed"]),
+                highs_dns=(None if not h["feasible"] else float(h["dns"])))
+
+
+def golden_from_reference(ref):
+    import scipy.io as sio
+    m = sio.loadmat(os.path.join(ref, "Montecarlo_nsq_single", "reliability_results.mat"))
+    csv = np.loadtxt(os.path.join(ref, "Montecarlo_nsq_single", "nodal_results.csv"),
+                     delimiter=",", skiprows=1)
+    out = dict(
+        source="Montecarlo_nsq_single/reliability_results.mat + nodal_results.csv (nsqMain.m:398-405)",
+        n_samples=100000, samples_per_batch=100,
+        accumulated_edns=float(m["accumulated_edns"].ravel()[0]),
+        accumulated_lole=float(m["accumulated_lole"].ravel()[0]),
+        nodal_eens=[float(v) for v in m["nodal_eens"].ravel()],
+        comp_importance=[float(v) for v in m["comp_importance"].ravel()],
+        beta_history=[float(v) for v in m["beta_history"].ravel()],
+        edns_history=[float(v) for v in m["edns_history"].ravel()],
+        nodal_results_csv_eens_mwh_yr=[float(v) for v in csv[:, 1]],
+    )
+    with open(os.path.join(HERE, "nsq_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("nsq_golden.json: EDNS", out["accumulated_edns"], "LOLE", out["accumulated_lole"])
+
+
+SPECIAL = [
+    [],                          # all up
+    [22, 32], [23, 32], [22, 23], [21, 22, 23],      # big-unit outages
+    [33 + 10],                   # L11 (7-8) out: bus 7 isolated (fact 11)
+    [33 + 10, 23], [33 + 10, 8, 9, 10],
+    [33 + 30, 33 + 37],          # L31 + L38: bus 22 isolated with 6 x U50, no load
+    [33 + 6, 33 + 26],           # L7 + L27: bus 24 isolated, no injection at all
+    [33 + 0, 33 + 1, 33 + 2],    # bus 1 isolated (L1,L2,L3)
+    [33 + 1, 33 + 5, 33 + 6],    # buses {3, 24} islanded via L2, L6, L7 out?  (3-9 is L6, 3-24 L7, 1-3 L2)
+    [33 + 27, 33 + 29, 33 + 30], # bus 17 isolated (L28, L30, L31)
+    [33 + 5], [33 + 8], [33 + 13, 33 + 14], [33 + 15, 33 + 16],
+    [12, 13, 22, 23, 32],        # heavy generation loss
+    list(range(0, 33)),          # every generator out (sync cond included in the mask)
+]
+
+
+def states_fixture(n_sample):
+    th = case24.thresholds_u32(CASE)
+    s = po.mc_sampling(th, 1, 0, n_sample)
+    uniq = np.unique(s, axis=0)
+    lists = [list(map(int, np.flatnonzero(u))) for u in uniq]
+    seen = {tuple(l) for l in lists}
+    for sp in SPECIAL:
+        if tuple(sorted(sp)) not in seen:
+            lists.append(sorted(sp))
+            seen.add(tuple(sorted(sp)))
+    with mp.Pool(8) as pool:
+        res0 = pool.map(_eval, [(l, po.REFERENCE_EMULATE) for l in lists], chunksize=8)
+        res1 = pool.map(_eval, [(l, po.PHYSICAL) for l in lists], chunksize=8)
+    out = dict(description="state -> oracle results; failed = 0-based component indices "
+                           "(0..32 generators, 33..70 branches)",
+               seed=1, n_sample=n_sample, ncomp=CASE.ncomp,
+               states=[dict(failed=l, emulate=a, physical=b) for l, a, b in zip(lists, res0, res1)])
+    with open(os.path.join(HERE, "states_fixture.json"), "w") as f:
+        json.dump(out, f)
+    bad = [x for x in out["states"] if x["physical"]["highs_dns"] is not None
+           and abs(x["physical"]["highs_dns"] - x["physical"]["dns"]) > 1e-5]
+    print("states_fixture.json:", len(lists), "states; MIPS-vs-HiGHS mismatches:", len(bad))
+
+
+def nsq_fixture(n):
+    """nsqMain.m:208-318 in its own database form, batch = 100."""
+    th = case24.thresholds_u32(CASE)
+    s = po.mc_sampling(th, 1, 0, n)
+    uniq, inv, counts = np.unique(s, axis=0, return_inverse=True, return_counts=True)
+    lists = [list(map(int, np.flatnonzero(u))) for u in uniq]
+    out = dict(seed=1, n=n, hours_per_year=8760.0)
+    for name, pol in (("emulate", po.REFERENCE_EMULATE), ("physical", po.PHYSICAL)):
+        with mp.Pool(8) as pool:
+            res = pool.map(_eval, [(l, pol) for l in lists], chunksize=16)
+        dns = np.array([r["dns"] for r in res])
+        nodal = np.array([r["nodal"] for r in res])
+        flag = (dns > 1e-4).astype(float)                                   # nsqMain.m:270
+        edns = float((counts * dns).sum() / n)                              # :286-287
+        plc = float((counts * flag).sum() / n)                              # :295-296
+        lole = plc * 8760.0                                                 # :290-292
+        beta = float(np.sqrt((counts * (dns - edns) ** 2).sum()) / n / edns)  # :299-301
+        nodal_eens = (counts[:, None] * nodal).sum(0) / n                    # :348-349
+        fw = counts * flag
+        imp = (uniq.astype(float).T @ fw) / fw.sum()                        # :366-376
+        out[name] = dict(edns=edns, plc=plc, lole=lole, beta=beta,
+                         nodal_eens=[float(v) for v in nodal_eens],
+                         comp_importance=[float(v) for v in imp],
+                         n_fail=int((counts * flag).sum()),
+                         n_singular=int(sum(c for c, r in zip(counts, res) if r["status"] == po.ST_SINGULAR)),
+                         sum_iters=int(sum(c * r["iters"] for c, r in zip(counts, res))),
+                         n_distinct=len(lists))
+        print(name, "EDNS", edns, "PLC", plc, "beta", beta)
+    with open(os.path.join(HERE, "nsq_seed1_1e5.json"), "w") as f:
+        json.dump(out, f)
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--reference", default="/root/reference")
+    ap.add_argument("--n-states-sample", type=int, default=3000)
+    ap.add_argument("--n-nsq", type=int, default=100000)
+    a = ap.parse_args()
+    golden_from_reference(a.reference)
+    states_fixture(a.n_states_sample)
+    nsq_fixture(a.n_nsq)
