@@ -93,7 +93,7 @@ def preprocess(case, state, policy):
     for root in ([] if singular else np.unique(lab)):
         members = np.flatnonzero(lab == root)
         inj_here = [j for j in range(case.ninj) if inj_on[j] and lab[case.inj_bus[j]] == root]
-        pin = case.ref_bus if root == ref_lab else int(members.min())   # rule 1
+        pin = case.ref_bus if root == ref_lab else int(members.max())   # rule 1
         if root != ref_lab:
             pins.append(pin)
         has_load = any(j >= ng for j in inj_here)

@@ -227,7 +227,8 @@ static pre_info preprocess(const relmc_case_desc* c, const uint8_t* st, int poli
     int ref_lab = w->lab[c->ref_bus];
     for (int root = 0; root < nb; ++root) {
         if (w->lab[root] != root) continue;
-        int pin = root == ref_lab ? c->ref_bus : root;
+        int pin = c->ref_bus;            /* rule 1: reference bus, else the island's highest bus */
+        if (root != ref_lab) for (int i = 0; i < nb; ++i) if (w->lab[i] == root) pin = i;
         w->pin[pin] = 1;
         int n_inj = 0, n_load = 0, n_gen = 0, n_free = 0; double lo_sum = 0;
 #define IN_ISLAND(j) (w->inj_on[j] && w->lab[c->inj_bus[j]] == root)

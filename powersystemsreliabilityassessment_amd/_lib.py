@@ -1,0 +1,103 @@
+"""Loader for the HIP shared library (csrc/librelmc.so, C ABI of include/relmc.h).
+
+Fails loudly when the library is missing or cannot be loaded: this package has no CPU
+evaluation path (the CPU restatement under ``oracle/`` is test infrastructure and is never
+imported from here).
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+import subprocess
+
+from . import _abi
+
+_CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
+LIB_PATH = os.path.join(_CSRC, "librelmc.so")
+
+# every symbol include/relmc.h declares (checked at load time and by tests/test_abi.py)
+EXPORTS = [
+    "relmc_ctx_create", "relmc_ctx_destroy", "relmc_last_error", "relmc_version",
+    "relmc_solver_opts_default", "relmc_nsq_opts_default", "relmc_case_load",
+    "relmc_case_thresholds", "relmc_mc_sampling", "relmc_mc_sampling_dev",
+    "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate",
+    "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
+    "relmc_nsq_run",
+]
+
+
+class RelmcLibraryError(RuntimeError):
+    pass
+
+
+def build(verbose: bool = False) -> str:
+    """Compile the HIP extension for gfx950 in-tree (hipcc cross-compiles without a GPU)."""
+    cmd = ["make", "-C", _CSRC, "librelmc.so"]
+    subprocess.check_call(cmd, stdout=None if verbose else subprocess.DEVNULL)
+    return LIB_PATH
+
+
+_lib = None
+
+
+def load():
+    """ctypes handle with argtypes set.  Raises RelmcLibraryError if the extension is absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise RelmcLibraryError(
+            f"HIP extension not built: {LIB_PATH} is missing. Run "
+            f"`python -c 'import __graft_entry__ as g; g.build()'` (or `make -C {_CSRC}`); "
+            "there is no CPU fallback.")
+    try:
+        L = C.CDLL(LIB_PATH)
+    except OSError as e:  # pragma: no cover - depends on the machine
+        raise RelmcLibraryError(f"cannot load {LIB_PATH}: {e}") from e
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise RelmcLibraryError(f"{LIB_PATH} lacks symbols {missing}")
+    vp = C.c_void_p
+    u8p, dp, i32p = _abi.c_uint8_p, _abi.c_double_p, _abi.c_int32_p
+    L.relmc_ctx_create.argtypes = [C.c_int32, C.POINTER(vp)]
+    L.relmc_ctx_create.restype = C.c_int32
+    L.relmc_ctx_destroy.argtypes = [vp]
+    L.relmc_ctx_destroy.restype = None
+    L.relmc_last_error.argtypes = [vp]
+    L.relmc_last_error.restype = C.c_char_p
+    L.relmc_version.restype = C.c_char_p
+    L.relmc_solver_opts_default.argtypes = [C.POINTER(_abi.SolverOpts)]
+    L.relmc_solver_opts_default.restype = None
+    L.relmc_nsq_opts_default.argtypes = [C.POINTER(_abi.NsqOpts)]
+    L.relmc_nsq_opts_default.restype = None
+    L.relmc_case_load.argtypes = [vp, C.POINTER(_abi.CaseDesc)]
+    L.relmc_case_load.restype = C.c_int32
+    L.relmc_case_thresholds.argtypes = [vp, _abi.c_uint32_p]
+    L.relmc_case_thresholds.restype = C.c_int32
+    L.relmc_mc_sampling.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, u8p]
+    L.relmc_mc_sampling.restype = C.c_int32
+    L.relmc_mc_sampling_dev.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, vp]
+    L.relmc_mc_sampling_dev.restype = C.c_int32
+    L.relmc_mc_simulation.argtypes = [vp, u8p, C.c_int64, C.POINTER(_abi.SolverOpts), dp, dp, i32p, i32p]
+    L.relmc_mc_simulation.restype = C.c_int32
+    L.relmc_mc_simulation_dev.argtypes = [vp, vp, C.c_int64, C.POINTER(_abi.SolverOpts), vp, vp, vp, vp]
+    L.relmc_mc_simulation_dev.restype = C.c_int32
+    L.relmc_nsq_accumulate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts),
+                                       C.POINTER(_abi.Acc)]
+    L.relmc_nsq_accumulate.restype = C.c_int32
+    L.relmc_last_kernel_ms.argtypes = [vp, _abi.c_double_p]
+    L.relmc_last_kernel_ms.restype = C.c_int32
+    L.relmc_acc_zero.argtypes = [C.POINTER(_abi.Acc)]
+    L.relmc_acc_zero.restype = None
+    L.relmc_acc_merge.argtypes = [C.POINTER(_abi.Acc), C.POINTER(_abi.Acc)]
+    L.relmc_acc_merge.restype = None
+    L.relmc_nsq_indices.argtypes = [C.POINTER(_abi.Acc), C.c_int32, C.c_int32, C.c_double,
+                                    C.POINTER(_abi.Indices)]
+    L.relmc_nsq_indices.restype = None
+    L.relmc_nsq_run.argtypes = [vp, C.POINTER(_abi.NsqOpts), C.POINTER(_abi.NsqResult)]
+    L.relmc_nsq_run.restype = C.c_int32
+    if hasattr(L, "relmc_dpp_probe"):
+        L.relmc_dpp_probe.argtypes = [vp, dp, dp]
+        L.relmc_dpp_probe.restype = C.c_int32
+    _lib = L
+    return L

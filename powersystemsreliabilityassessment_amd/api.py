@@ -1,0 +1,254 @@
+"""Host-side mirror of the reference's operator interface for the HL2 non-sequential path.
+
+The reference exposes three MATLAB entry points; the methods below keep their
+names, argument meaning and outputs and route every evaluation to the HIP library through
+the C ABI of include/relmc.h:
+
+  mc_sampling(failure_probabilities, num_samples, numGenerators, numLines)
+      -> eqstatus [num_samples x (Ng+Nl)], 1 = failed        (mc_sampling.m:2)
+  mc_simulation(component_states, TestSystem, mpopt, numGenerators, numLines)
+      -> (dns, nodal_dns[1 x Nb])                             (mc_simulation.m:1)
+  nsqMain(...)   the `while beta > beta_limit` loop + post-processing (nsqMain.m:208-406)
+
+Differences that are deliberate and documented in DESIGN.md: the sampler is a counter-based
+RNG keyed by (seed, global scenario index) instead of MATLAB's unseeded global stream, and
+mc_simulation accepts a whole matrix of states (the reference's parfor, nsqMain.m:257-263).
+"""
+from __future__ import annotations
+
+import ctypes as C
+from dataclasses import dataclass, field
+
+import numpy as np
+
+from . import _abi, _lib, case24
+
+REFERENCE_EMULATE = _abi.RELMC_REFERENCE_EMULATE
+PHYSICAL = _abi.RELMC_PHYSICAL
+
+
+class RelmcError(RuntimeError):
+    pass
+
+
+def mpoption(singular_policy: int = REFERENCE_EMULATE, **overrides) -> _abi.SolverOpts:
+    """Solver options = what nsqMain.m:185-186 asks MATPOWER for (DC model, MIPS, flow limits on),
+    i.e. MIPS defaults: feastol 5e-6, gradtol/comptol/costtol 1e-6, max_it 150."""
+    o = _abi.default_solver_opts(singular_policy)
+    for k, v in overrides.items():
+        if not hasattr(o, k):
+            raise TypeError(f"unknown solver option {k!r}")
+        setattr(o, k, v)
+    return o
+
+
+@dataclass
+class NsqResult:
+    """Workspace variables nsqMain leaves behind (nsqMain.m:282-308, 348-349, 366-376, 404-405)."""
+    accumulated_edns: float
+    accumulated_lole: float
+    plc: float
+    current_beta: float
+    current_iteration: int
+    nodal_eens: np.ndarray
+    comp_importance: np.ndarray
+    beta_history: np.ndarray
+    edns_history: np.ndarray
+    lole_history: np.ndarray
+    plc_history: np.ndarray
+    converged: bool
+    mean_iters: float
+    n_singular: int
+    n_infeasible: int
+    n_nonconverged: int
+    elapsed_time: float
+    kernel_seconds: float
+    acc: _abi.Acc = field(repr=False, default=None)
+
+    def write_nodal_csv(self, path: str, hours_per_year: float = 8760.0) -> None:
+        """nodal_results.csv exactly as nsqMain.m:398-400 writes it (BusID, EENS_MWh_yr)."""
+        with open(path, "w") as f:
+            f.write("BusID,EENS_MWh_yr\n")
+            for i, v in enumerate(self.nodal_eens):
+                f.write(f"{i + 1},{float(v) * hours_per_year:.15g}\n")
+
+    def save_mat(self, path: str) -> None:
+        """reliability_results.mat with the variables of nsqMain.m:404-405."""
+        from scipy.io import savemat
+        savemat(path, dict(accumulated_edns=self.accumulated_edns, accumulated_lole=self.accumulated_lole,
+                           nodal_eens=self.nodal_eens[None, :], comp_importance=self.comp_importance[:, None],
+                           beta_history=self.beta_history[None, :], edns_history=self.edns_history[None, :]))
+
+
+class Engine:
+    """One context = one GPU (one process per GPU).  Owns the device-resident case tables."""
+
+    def __init__(self, case: case24.Case | None = None, device: int = 0):
+        self.L = _lib.load()
+        h = C.c_void_p()
+        rc = self.L.relmc_ctx_create(int(device), C.byref(h))
+        if rc != 0:
+            raise RelmcError(f"relmc_ctx_create(device={device}) failed with {rc}: no usable HIP device "
+                             "(this package has no CPU fallback)")
+        self._h = h
+        self.device = device
+        self.case = None
+        self._holder = None
+        self.load_case(case or case24.rts24())
+
+    # -- lifetime ---------------------------------------------------------------------------
+    def close(self):
+        if getattr(self, "_h", None):
+            self.L.relmc_ctx_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass
+
+    def _check(self, rc, what):
+        if rc != 0:
+            msg = self.L.relmc_last_error(self._h)
+            raise RelmcError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
+
+    # -- setup ------------------------------------------------------------------------------
+    def load_case(self, case: case24.Case):
+        holder = _abi.CaseHolder(case)
+        self._check(self.L.relmc_case_load(self._h, C.byref(holder.desc)), "relmc_case_load")
+        self.case, self._holder = case, holder
+
+    def thresholds(self) -> np.ndarray:
+        out = np.zeros(self.case.ncomp, dtype=np.uint32)
+        self._check(self.L.relmc_case_thresholds(self._h, out.ctypes.data_as(_abi.c_uint32_p)),
+                    "relmc_case_thresholds")
+        return out
+
+    # -- mc_sampling.m:2 ----------------------------------------------------------------------
+    def mc_sampling(self, failure_probabilities=None, num_samples: int = 100, numGenerators=None,
+                    numLines=None, *, seed: int = 1, first_index: int = 0) -> np.ndarray:
+        ng = self.case.ng if numGenerators is None else int(numGenerators)
+        nl = self.case.nl if numLines is None else int(numLines)
+        if (ng, nl) != (self.case.ng, self.case.nl):
+            raise ValueError("numGenerators/numLines do not match the loaded case")
+        if failure_probabilities is not None:
+            fp = np.asarray(failure_probabilities, dtype=np.float64).ravel()
+            if fp.size != ng + nl:
+                raise ValueError("failure_probabilities must have numGenerators+numLines entries")
+            if not np.array_equal(fp, self.case.unavail):
+                import dataclasses
+                self.load_case(dataclasses.replace(self.case, unavail=fp.copy()))
+        n = int(num_samples)
+        out = np.zeros((n, ng + nl), dtype=np.uint8)
+        self._check(self.L.relmc_mc_sampling(self._h, int(seed), int(first_index), n,
+                                             out.ctypes.data_as(_abi.c_uint8_p)), "relmc_mc_sampling")
+        return out
+
+    # -- mc_simulation.m:1 (batched) ------------------------------------------------------------
+    def mc_simulation(self, component_states, TestSystem=None, mpopt=None, numGenerators=None,
+                      numLines=None, *, return_info: bool = False):
+        """Returns (dns, nodal_dns).  For a single state: scalar dns and a [Nb] vector, as the
+        reference; for a matrix of states: dns[n] and nodal_dns[n, Nb]."""
+        if TestSystem is not None and TestSystem is not self.case:
+            self.load_case(TestSystem)
+        st = np.asarray(component_states)
+        single = st.ndim == 1
+        st = np.ascontiguousarray(st.reshape(-1, self.case.ncomp) != 0, dtype=np.uint8)
+        n = st.shape[0]
+        o = mpopt if mpopt is not None else mpoption()
+        dns = np.zeros(n)
+        nodal = np.zeros((n, self.case.nb))
+        status = np.zeros(n, dtype=np.int32)
+        iters = np.zeros(n, dtype=np.int32)
+        self._check(self.L.relmc_mc_simulation(self._h, st.ctypes.data_as(_abi.c_uint8_p), n, C.byref(o),
+                                               dns.ctypes.data_as(_abi.c_double_p),
+                                               nodal.ctypes.data_as(_abi.c_double_p),
+                                               status.ctypes.data_as(_abi.c_int32_p),
+                                               iters.ctypes.data_as(_abi.c_int32_p)), "relmc_mc_simulation")
+        if single:
+            res = (float(dns[0]), nodal[0])
+        else:
+            res = (dns, nodal)
+        if return_info:
+            return res + (dict(status=status, iters=iters),)
+        return res
+
+    def mc_simulation_dev(self, states_ptr: int, n: int, dns_ptr: int, nodal_ptr: int = 0,
+                          status_ptr: int = 0, iters_ptr: int = 0, mpopt=None):
+        """Same with every buffer already in this GPU's HBM (raw device addresses, e.g. tensor.data_ptr())."""
+        o = mpopt if mpopt is not None else mpoption()
+        self._check(self.L.relmc_mc_simulation_dev(self._h, states_ptr, int(n), C.byref(o), dns_ptr,
+                                                   nodal_ptr or None, status_ptr or None, iters_ptr or None),
+                    "relmc_mc_simulation_dev")
+
+    # -- fused loop body ---------------------------------------------------------------------
+    def nsq_accumulate(self, seed: int, first_index: int, n: int, mpopt=None) -> _abi.Acc:
+        o = mpopt if mpopt is not None else mpoption()
+        acc = _abi.Acc()
+        self._check(self.L.relmc_nsq_accumulate(self._h, int(seed), int(first_index), int(n), C.byref(o),
+                                                C.byref(acc)), "relmc_nsq_accumulate")
+        return acc
+
+    def last_kernel_ms(self) -> float:
+        ms = C.c_double()
+        self._check(self.L.relmc_last_kernel_ms(self._h, C.byref(ms)), "relmc_last_kernel_ms")
+        return ms.value
+
+    def indices(self, acc: _abi.Acc, hours_per_year: float = 8760.0) -> _abi.Indices:
+        out = _abi.Indices()
+        self.L.relmc_nsq_indices(C.byref(acc), self.case.nb, self.case.ncomp, hours_per_year, C.byref(out))
+        return out
+
+    # -- nsqMain.m:208-406 ---------------------------------------------------------------------
+    def nsqMain(self, beta_limit: float = 0.0017, max_iterations: int = 100000,
+                samples_per_batch: int = 100, *, seed: int = 1, mpopt=None,
+                hours_per_year: float = 8760.0) -> NsqResult:
+        """Defaults are the reference's (nsqMain.m:60-62).  On a GPU a batch of 100 is tiny; pass
+        samples_per_batch >= 1e5 for throughput — the estimators do not depend on the batch size."""
+        o = _abi.NsqOpts()
+        self.L.relmc_nsq_opts_default(C.byref(o))
+        o.beta_limit, o.max_samples, o.batch = float(beta_limit), int(max_iterations), int(samples_per_batch)
+        o.seed, o.hours_per_year = int(seed), float(hours_per_year)
+        if mpopt is not None:
+            o.solver = mpopt
+        ncp = (int(max_iterations) + int(samples_per_batch) - 1) // int(samples_per_batch)
+        hist = [np.zeros(ncp) for _ in range(4)]
+        o.history_cap = ncp
+        o.beta_history, o.edns_history, o.lole_history, o.plc_history = (
+            h.ctypes.data_as(_abi.c_double_p) for h in hist)
+        res = _abi.NsqResult()
+        self._check(self.L.relmc_nsq_run(self._h, C.byref(o), C.byref(res)), "relmc_nsq_run")
+        k = int(res.checkpoints)
+        nb, nc = self.case.nb, self.case.ncomp
+        return NsqResult(
+            accumulated_edns=res.idx.edns, accumulated_lole=res.idx.lole, plc=res.idx.plc,
+            current_beta=res.idx.beta, current_iteration=int(res.idx.n),
+            nodal_eens=np.array(res.idx.nodal_eens[:nb]), comp_importance=np.array(res.idx.comp_importance[:nc]),
+            beta_history=hist[0][:k], edns_history=hist[1][:k], lole_history=hist[2][:k], plc_history=hist[3][:k],
+            converged=bool(res.converged), mean_iters=res.idx.mean_iters, n_singular=int(res.acc.n_singular),
+            n_infeasible=int(res.acc.n_infeasible), n_nonconverged=int(res.acc.n_nonconverged),
+            elapsed_time=res.wall_seconds, kernel_seconds=res.kernel_seconds, acc=res.acc)
+
+
+# ---- module-level functions with the reference's names (default engine on RTS-24) ---------------
+_default_engine: Engine | None = None
+
+
+def default_engine() -> Engine:
+    global _default_engine
+    if _default_engine is None:
+        _default_engine = Engine()
+    return _default_engine
+
+
+def mc_sampling(failure_probabilities, num_samples, numGenerators, numLines, **kw):
+    return default_engine().mc_sampling(failure_probabilities, num_samples, numGenerators, numLines, **kw)
+
+
+def mc_simulation(component_states, TestSystem=None, mpopt=None, numGenerators=None, numLines=None, **kw):
+    return default_engine().mc_simulation(component_states, TestSystem, mpopt, numGenerators, numLines, **kw)
+
+
+def nsqMain(**kw):
+    return default_engine().nsqMain(**kw)

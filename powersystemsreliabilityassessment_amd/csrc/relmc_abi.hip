@@ -1,0 +1,495 @@
+// relmc_abi.hip — the C ABI of include/relmc.h on top of the gfx950 kernels.
+// Host code only orchestrates: case tables -> HBM, launches on the context's stream, HIP-event
+// timing, deterministic partial reduction on the device, estimator arithmetic on the host.
+// There is no CPU evaluation path in this library.
+#include <hip/hip_runtime.h>
+
+#include <chrono>
+#include <cmath>
+#include <cstdio>
+#include <cstring>
+#include <new>
+#include <string>
+#include <vector>
+
+#include "../../include/relmc.h"
+#include "relmc_kernels.hip"
+
+using namespace relmc;
+
+static_assert(sizeof(DevAcc) == sizeof(relmc_acc), "device accumulator image must match relmc_acc");
+
+struct relmc_ctx {
+    int device = -1;
+    hipStream_t stream = nullptr;
+    hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    bool has_case = false;
+    DevCase hcase;
+    DevCase* dcase = nullptr;
+    Partial* dpartial = nullptr;
+    int partial_blocks = 0;
+    DevAcc* dacc = nullptr;
+    int num_cu = 0;
+    int blocks_per_cu = 0;
+    double last_kernel_ms = 0.0;
+    std::string err;
+};
+
+namespace {
+
+const char* kNoCtx = "relmc: null context";
+
+int fail(relmc_ctx* ctx, int code, const std::string& msg)
+{
+    if (ctx) ctx->err = msg;
+    return code;
+}
+
+#define HIP_TRY(ctx, expr)                                                                       \
+    do {                                                                                         \
+        hipError_t e_ = (expr);                                                                  \
+        if (e_ != hipSuccess)                                                                    \
+            return fail(ctx, RELMC_ERR_HIP, std::string(#expr) + ": " + hipGetErrorString(e_)); \
+    } while (0)
+
+EvalArgs make_args(const relmc_solver_opts& o)
+{
+    EvalArgs a;
+    std::memset(&a, 0, sizeof(a));
+    a.policy = o.singular_policy; a.max_it = o.max_it;
+    a.feastol = o.feastol; a.gradtol = o.gradtol; a.comptol = o.comptol; a.costtol = o.costtol;
+    a.xi = o.xi; a.sigma = o.sigma; a.z0 = o.z0; a.alpha_min = o.alpha_min; a.max_stepsize = o.max_stepsize;
+    return a;
+}
+
+int grid_for(relmc_ctx* ctx, int64_t n)
+{
+    const int64_t groups = (n + 3) / 4;
+    int64_t g = (int64_t)ctx->num_cu * ctx->blocks_per_cu;
+    if (g > groups) g = groups;
+    if (g < 1) g = 1;
+    return (int)g;
+}
+
+int ensure_partial(relmc_ctx* ctx, int blocks)
+{
+    if (blocks <= ctx->partial_blocks) return RELMC_OK;
+    if (ctx->dpartial) (void)hipFree(ctx->dpartial);
+    ctx->dpartial = nullptr; ctx->partial_blocks = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->dpartial, sizeof(Partial) * 64 * (size_t)blocks));
+    ctx->partial_blocks = blocks;
+    return RELMC_OK;
+}
+
+template <bool FROM_RNG, bool WRITE_OUT>
+int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
+{
+    const int blocks = grid_for(ctx, a.n);
+    int rc = ensure_partial(ctx, blocks);
+    if (rc) return rc;
+    a.partial = ctx->dpartial;
+    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->dcase, a);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    *blocks_out = blocks;
+    return RELMC_OK;
+}
+
+int finish_timing(relmc_ctx* ctx)
+{
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    float ms = 0.f;
+    HIP_TRY(ctx, hipEventElapsedTime(&ms, ctx->ev0, ctx->ev1));
+    ctx->last_kernel_ms = ms;
+    return RELMC_OK;
+}
+
+}  // namespace
+
+extern "C" {
+
+const char* relmc_version(void) { return "relmc 0.1 (gfx950; 16-lane DPP-row IPM, KKT in VGPRs)"; }
+
+const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
+
+int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
+{
+    if (!out) return RELMC_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RELMC_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return RELMC_ERR_INVALID;
+    relmc_ctx* ctx = new (std::nothrow) relmc_ctx();
+    if (!ctx) return RELMC_ERR_INVALID;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc(&ctx->dcase, sizeof(DevCase)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess) {
+        delete ctx;
+        return RELMC_ERR_NO_DEVICE;
+    }
+    ctx->num_cu = prop.multiProcessorCount;
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<true, false>, 64, 0) != hipSuccess || bpc < 1) bpc = 4;
+    ctx->blocks_per_cu = bpc;
+    *out = ctx;
+    return RELMC_OK;
+}
+
+void relmc_ctx_destroy(relmc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->dpartial) (void)hipFree(ctx->dpartial);
+    if (ctx->dcase) (void)hipFree(ctx->dcase);
+    if (ctx->dacc) (void)hipFree(ctx->dacc);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void relmc_solver_opts_default(relmc_solver_opts* o)
+{
+    if (!o) return;
+    o->singular_policy = RELMC_REFERENCE_EMULATE;
+    o->max_it = 150;
+    o->feastol = 5e-6; o->gradtol = 1e-6; o->comptol = 1e-6; o->costtol = 1e-6;
+    o->xi = 0.99995; o->sigma = 0.1; o->z0 = 1.0; o->alpha_min = 1e-8; o->max_stepsize = 1e10;
+}
+
+void relmc_nsq_opts_default(relmc_nsq_opts* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->beta_limit = 0.0017;       /* nsqMain.m:60 */
+    o->max_samples = 100000;      /* nsqMain.m:61 */
+    o->batch = 100;               /* nsqMain.m:62 */
+    o->seed = 1;
+    o->hours_per_year = 8760.0;   /* nsqMain.m:292 */
+    relmc_solver_opts_default(&o->solver);
+}
+
+// Build the device tables (tile padding, pair map, incidence lists, thresholds) from the plain
+// case description.  Mirrors what nsqMain.m:42-167 prepares once before its Monte Carlo loop.
+int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!d || !d->bus_pd || !d->inj_bus || !d->inj_pmin || !d->inj_pmax || !d->inj_cost || !d->br_from ||
+        !d->br_to || !d->br_b || !d->br_rate || !d->unavail || !d->always_up)
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: null field in case description");
+    const int nb = d->nb, ng = d->ng, nl = d->nl, nd = d->nd, ninj = ng + nd, ncomp = ng + nl;
+    if (nb < 1 || ng < 0 || nl < 0 || nd < 0 || d->ref_bus < 0 || d->ref_bus >= nb || !(d->base_mva > 0))
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
+    if (nb > NBT || nl > NLT || ninj > NIT || ncomp > NCOMPMAX)
+        return fail(ctx, RELMC_ERR_UNSUPPORTED,
+                    "relmc_case_load: case exceeds the compiled tile (24 buses, 48 lines, 64 injections)");
+    DevCase& C = ctx->hcase;
+    std::memset(&C, 0, sizeof(C));
+    C.nb = nb; C.ng = ng; C.nl = nl; C.nd = nd; C.ninj = ninj; C.ncomp = ncomp;
+    C.base_mva = d->base_mva; C.total_load = d->total_load;
+    // Internal bus numbering = position in the elimination sequence (gen_elim.py: internal buses
+    // 16..23 first, then 0..15): external buses in increasing order, the reference bus moved to the
+    // very end (internal 15), so that a fixed angle is always eliminated last in its island.
+    int ext2int[NBT];
+    {
+        int pos = 0;
+        for (int i = 0; i < NBT; ++i) { C.b_ext[i] = 0xff; C.b_int[i] = 0xff; }
+        for (int e = 0; e < nb; ++e) {
+            const int k = e == d->ref_bus ? NBT - 1 : pos++;
+            const int ii = k < 8 ? 16 + k : k - 8;
+            ext2int[e] = ii; C.b_ext[ii] = (uint8_t)e; C.b_int[e] = (uint8_t)ii;
+            C.exist_mask |= 1u << ii;
+        }
+    }
+    C.ref_bus = ext2int[d->ref_bus];
+    for (int i = 0; i < NBT; ++i) { C.b_vinj[i] = -1; for (int c = 0; c < NBT; ++c) C.T[i][c] = (uint8_t)(i == c ? DIAG0 + i : ZIDX); }
+    for (int l = 0; l < NLT; ++l) C.l_partner[l] = -1;
+    // lines, bus pairs
+    int pair_of[NBT][NBT];
+    for (int i = 0; i < NBT; ++i) for (int c = 0; c < NBT; ++c) pair_of[i][c] = -1;
+    int npair = 0;
+    std::vector<int> pair_lines(PMAX, 0), pair_owner(PMAX, -1);
+    for (int l = 0; l < nl; ++l) {
+        if (d->br_from[l] < 0 || d->br_from[l] >= nb || d->br_to[l] < 0 || d->br_to[l] >= nb ||
+            d->br_from[l] == d->br_to[l] || !(d->br_b[l] == d->br_b[l]))
+            return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad branch end points");
+        const int f = ext2int[d->br_from[l]], t = ext2int[d->br_to[l]];
+        const int a = f < t ? f : t, b = f < t ? t : f;
+        uint32_t flags = LF_EXISTS;
+        if (d->br_rate[l] != 0.0) flags |= LF_LIMITED;
+        int p = pair_of[a][b];
+        if (p < 0) {
+            if (npair >= PMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 48 distinct bus pairs");
+            p = npair++;
+            pair_of[a][b] = p; pair_owner[p] = l; flags |= LF_OWNER;
+            C.T[a][b] = (uint8_t)p; C.T[b][a] = (uint8_t)(PMAX + p);
+        } else {
+            if (pair_lines[p] >= 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than two parallel lines");
+            C.l_partner[pair_owner[p]] = l;
+        }
+        pair_lines[p]++;
+        C.l_b[l] = d->br_b[l];
+        C.l_rate[l] = d->br_rate[l] / d->base_mva;
+        C.l_info[l] = (uint32_t)f | ((uint32_t)t << 8) | ((uint32_t)p << 16) | (flags << 24);
+        for (int side = 0; side < 2; ++side) {
+            const int bus = side ? t : f;
+            if (C.b_nline[bus] >= DEGMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 8 lines at a bus");
+            C.b_line[bus][C.b_nline[bus]++] = (uint8_t)(l | (side ? 0x80 : 0));
+        }
+    }
+    C.npair = npair;
+    // injections
+    for (int j = 0; j < ninj; ++j) {
+        if (d->inj_bus[j] < 0 || d->inj_bus[j] >= nb) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad injection bus");
+        const int bus = ext2int[d->inj_bus[j]];
+        C.i_lo[j] = d->inj_pmin[j] / d->base_mva;
+        C.i_hi[j] = d->inj_pmax[j] / d->base_mva;
+        C.i_cost[j] = d->inj_cost[j] * d->base_mva;
+        C.i_pmin_mw[j] = d->inj_pmin[j];
+        C.i_info[j] = (uint32_t)bus | ((j < ng ? IK_REAL : IK_VIRTUAL) << 8);
+        if (C.b_ninj[bus] >= BINJMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 8 injections at a bus");
+        C.b_inj[bus][C.b_ninj[bus]++] = (uint8_t)j;
+        if (j >= ng) {
+            if (C.b_vinj[bus] >= 0) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: two virtual generators at one bus");
+            C.b_vinj[bus] = (int8_t)j;
+        }
+    }
+    // Bernoulli thresholds: fail iff draw_u32 < floor(U * 2^32)   (mc_sampling.m:35, strict '<')
+    for (int k = 0; k < ncomp; ++k) {
+        double t = std::floor(d->unavail[k] * 4294967296.0);
+        if (!(t > 0)) t = 0;
+        if (t > 4294967295.0) t = 4294967295.0;
+        C.thr[k] = d->always_up[k] ? 0u : (uint32_t)t;   // mc_sampling.m:40-41
+    }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase, &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->has_case = true;
+    return RELMC_OK;
+}
+
+int32_t relmc_case_thresholds(const relmc_ctx* ctx, uint32_t* out)
+{
+    if (!ctx || !out) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return RELMC_ERR_NO_CASE;
+    std::memcpy(out, ctx->hcase.thr, sizeof(uint32_t) * ctx->hcase.ncomp);
+    return RELMC_OK;
+}
+
+int32_t relmc_mc_sampling_dev(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, uint8_t* eqstatus_dev)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_mc_sampling: no case loaded");
+    if (n < 0 || (n > 0 && !eqstatus_dev)) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_sampling: bad arguments");
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t total = n * ((ctx->hcase.ncomp + 3) / 4);
+    int64_t blocks = (total + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL(relmc_sampling_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->dcase, seed, first_index, n, eqstatus_dev);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RELMC_OK;
+}
+
+int32_t relmc_mc_sampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, uint8_t* eqstatus_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_mc_sampling: no case loaded");
+    if (n < 0 || (n > 0 && !eqstatus_host)) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_sampling: bad arguments");
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint8_t* dbuf = nullptr;
+    const size_t bytes = (size_t)n * ctx->hcase.ncomp;
+    HIP_TRY(ctx, hipMalloc(&dbuf, bytes));
+    int rc = relmc_mc_sampling_dev(ctx, seed, first_index, n, dbuf);
+    if (rc == RELMC_OK && hipMemcpy(eqstatus_host, dbuf, bytes, hipMemcpyDeviceToHost) != hipSuccess)
+        rc = fail(ctx, RELMC_ERR_HIP, "relmc_mc_sampling: device-to-host copy failed");
+    (void)hipFree(dbuf);
+    return rc;
+}
+
+int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64_t n, const relmc_solver_opts* opts,
+                                double* dns_dev, double* nodal_dev, int32_t* status_dev, int32_t* iters_dev)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_mc_simulation: no case loaded");
+    if (n < 0 || (n > 0 && (!states_dev || !dns_dev))) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_simulation: bad arguments");
+    if (n == 0) return RELMC_OK;
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    EvalArgs a = make_args(o);
+    a.n = n; a.states = states_dev; a.dns = dns_dev; a.nodal = nodal_dev; a.status = status_dev; a.iters = iters_dev;
+    int blocks = 0;
+    int rc = launch_eval<false, true>(ctx, a, &blocks);
+    if (rc) return rc;
+    return finish_timing(ctx);
+}
+
+int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t n, const relmc_solver_opts* opts,
+                            double* dns_host, double* nodal_host, int32_t* status_host, int32_t* iters_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_mc_simulation: no case loaded");
+    if (n < 0 || (n > 0 && (!states_host || !dns_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_simulation: bad arguments");
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ncomp = ctx->hcase.ncomp, nb = ctx->hcase.nb;
+    uint8_t* dst = nullptr; double* ddns = nullptr; double* dnod = nullptr; int32_t* dstat = nullptr; int32_t* dit = nullptr;
+    int rc = RELMC_OK;
+    auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
+    if (hipMalloc(&dst, (size_t)n * ncomp) != hipSuccess || hipMalloc(&ddns, sizeof(double) * n) != hipSuccess ||
+        hipMalloc(&dnod, sizeof(double) * n * nb) != hipSuccess || hipMalloc(&dstat, sizeof(int32_t) * n) != hipSuccess ||
+        hipMalloc(&dit, sizeof(int32_t) * n) != hipSuccess) {
+        cleanup();
+        return fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: device allocation failed");
+    }
+    if (hipMemcpy(dst, states_host, (size_t)n * ncomp, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: H2D copy failed");
+    if (rc == RELMC_OK) rc = relmc_mc_simulation_dev(ctx, dst, n, opts, ddns, dnod, dstat, dit);
+    if (rc == RELMC_OK) {
+        bool ok = hipMemcpy(dns_host, ddns, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (nodal_host) ok = ok && hipMemcpy(nodal_host, dnod, sizeof(double) * n * nb, hipMemcpyDeviceToHost) == hipSuccess;
+        if (status_host) ok = ok && hipMemcpy(status_host, dstat, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (iters_host) ok = ok && hipMemcpy(iters_host, dit, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) rc = fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: D2H copy failed");
+    }
+    cleanup();
+    return rc;
+}
+
+int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
+                             relmc_acc* acc_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_accumulate: no case loaded");
+    if (n < 0 || !acc_out) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_accumulate: bad arguments");
+    relmc_acc_zero(acc_out);
+    if (n == 0) return RELMC_OK;
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    // a wavefront row counts its scenarios in 32 bits: split very large ranges
+    const int64_t kMaxPerLaunch = (int64_t)1 << 31;
+    double ms_total = 0.0;
+    for (int64_t done = 0; done < n;) {
+        const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
+        EvalArgs a = make_args(o);
+        a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
+        int blocks = 0;
+        int rc = launch_eval<true, false>(ctx, a, &blocks);
+        if (rc) return rc;
+        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks, ctx->dacc);
+        HIP_TRY(ctx, hipGetLastError());
+        relmc_acc part;
+        HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
+        rc = finish_timing(ctx);
+        if (rc) return rc;
+        ms_total += ctx->last_kernel_ms;
+        relmc_acc_merge(acc_out, &part);
+        done += m;
+    }
+    ctx->last_kernel_ms = ms_total;
+    return RELMC_OK;
+}
+
+int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms)
+{
+    if (!ctx || !ms) return RELMC_ERR_INVALID;
+    *ms = ctx->last_kernel_ms;
+    return RELMC_OK;
+}
+
+void relmc_acc_zero(relmc_acc* acc) { if (acc) std::memset(acc, 0, sizeof(*acc)); }
+
+void relmc_acc_merge(relmc_acc* d, const relmc_acc* s)
+{
+    if (!d || !s) return;
+    d->n += s->n; d->n_fail += s->n_fail; d->n_singular += s->n_singular; d->n_infeasible += s->n_infeasible;
+    d->n_nonconverged += s->n_nonconverged; d->sum_iters += s->sum_iters;
+    for (int k = 0; k < RELMC_MAX_COMP; ++k) d->comp_fail[k] += s->comp_fail[k];
+    d->sum_dns += s->sum_dns; d->sum_dns2 += s->sum_dns2;
+    for (int i = 0; i < RELMC_MAX_BUS; ++i) d->sum_nodal[i] += s->sum_nodal[i];
+}
+
+// nsqMain.m:286-301 (EDNS, LOLE, PLC, beta), :348-349 (nodal), :366-376 (component importance),
+// written for per-sample sums: the reference's count-weighted database sums are the same numbers.
+void relmc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out)
+{
+    if (!a || !out) return;
+    std::memset(out, 0, sizeof(*out));
+    out->n = a->n;
+    if (a->n <= 0) return;
+    const double N = (double)a->n;
+    out->edns = a->sum_dns / N;
+    out->plc = (double)a->n_fail / N;
+    out->lole = out->plc * hours;
+    out->eens = out->edns * hours;
+    double ss = a->sum_dns2 - N * out->edns * out->edns;
+    if (ss < 0) ss = 0;
+    out->beta = out->edns > 0 ? std::sqrt(ss) / N / out->edns : INFINITY;   // guard of SURVEY.md App. E (beta = NaN)
+    out->mean_iters = (double)a->sum_iters / N;
+    if (nb > RELMC_MAX_BUS) nb = RELMC_MAX_BUS;
+    if (ncomp > RELMC_MAX_COMP) ncomp = RELMC_MAX_COMP;
+    for (int i = 0; i < nb; ++i) out->nodal_eens[i] = a->sum_nodal[i] / N;
+    for (int k = 0; k < ncomp; ++k) out->comp_importance[k] = a->n_fail ? (double)a->comp_fail[k] / (double)a->n_fail : 0.0;
+}
+
+// nsqMain.m:208-318: batches until beta <= beta_limit or max_samples, then the post-processing of :345-376
+int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result* res)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_run: no case loaded");
+    if (!o || !res || o->batch <= 0 || o->max_samples <= 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_run: bad options");
+    std::memset(res, 0, sizeof(*res));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int nb = ctx->hcase.nb, ncomp = ctx->hcase.ncomp;
+    double beta = INFINITY, kernel_ms = 0.0;
+    int64_t done = 0, cp = 0;
+    while (beta > o->beta_limit && done < o->max_samples) {
+        const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;
+        relmc_acc part;
+        int rc = relmc_nsq_accumulate(ctx, o->seed, (uint64_t)done, m, &o->solver, &part);
+        if (rc) return rc;
+        kernel_ms += ctx->last_kernel_ms;
+        relmc_acc_merge(&res->acc, &part);
+        done += m;
+        relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
+        beta = res->idx.beta;
+        if (cp < o->history_cap) {
+            if (o->beta_history) o->beta_history[cp] = res->idx.beta;
+            if (o->edns_history) o->edns_history[cp] = res->idx.edns;
+            if (o->lole_history) o->lole_history[cp] = res->idx.lole;
+            if (o->plc_history) o->plc_history[cp] = res->idx.plc;
+        }
+        cp++;
+    }
+    res->checkpoints = cp;
+    res->converged = beta <= o->beta_limit ? 1 : 0;
+    res->kernel_seconds = kernel_ms * 1e-3;
+    res->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ctx->last_kernel_ms = kernel_ms;
+    return RELMC_OK;
+}
+
+// test hook: DPP semantics probe (tests/test_gpu_parity.py); in[64] -> out[384]
+int32_t relmc_dpp_probe(relmc_ctx* ctx, const double* in_host, double* out_host)
+{
+    if (!ctx || !in_host || !out_host) return RELMC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    double* din = nullptr; double* dout = nullptr;
+    HIP_TRY(ctx, hipMalloc(&din, sizeof(double) * 64));
+    HIP_TRY(ctx, hipMalloc(&dout, sizeof(double) * 384));
+    HIP_TRY(ctx, hipMemcpy(din, in_host, sizeof(double) * 64, hipMemcpyHostToDevice));
+    hipLaunchKernelGGL(relmc_dpp_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, din, dout);
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemcpy(out_host, dout, sizeof(double) * 384, hipMemcpyDeviceToHost));
+    (void)hipFree(din); (void)hipFree(dout);
+    return RELMC_OK;
+}
+
+}  // extern "C"

@@ -1,0 +1,89 @@
+"""Multi-GPU driver: scenarios shard by global index, one all-reduce per convergence check.
+
+SURVEY.md §8e: the reference's only parallelism is the `parfor` over sampled states
+(nsqMain.m:257-263); scenarios are i.i.d., so every super-batch [done, done+batch) of the global
+scenario index range is split contiguously across the ranks, each rank runs the fused
+sample -> evaluate -> reduce kernel on its slice, and the additive accumulators (relmc_acc,
+~390 words) are summed with ONE all-reduce (RCCL over xGMI when the process group is "nccl").
+Because the sampler is keyed by (seed, global index), the merged accumulators do not depend on
+the number of ranks (integers exactly, fp64 sums up to summation order).
+"""
+from __future__ import annotations
+
+import numpy as np
+
+from . import _abi
+
+
+def shard_range(start: int, count: int, rank: int, world: int):
+    """Contiguous slice of [start, start+count) owned by `rank`."""
+    lo = start + (count * rank) // world
+    hi = start + (count * (rank + 1)) // world
+    return lo, hi - lo
+
+
+def allreduce_acc(acc: _abi.Acc, device=None) -> _abi.Acc:
+    """Sum relmc_acc over the default process group (no-op without one)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return acc
+    ints, dbls = acc.to_arrays()
+    ti = torch.from_numpy(ints)
+    td = torch.from_numpy(dbls)
+    if dist.get_backend() == "nccl":
+        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
+        ti, td = ti.to(dev), td.to(dev)
+    dist.all_reduce(ti, op=dist.ReduceOp.SUM)
+    dist.all_reduce(td, op=dist.ReduceOp.SUM)
+    return _abi.Acc.from_arrays(ti.cpu().numpy(), td.cpu().numpy())
+
+
+def merge(a: _abi.Acc, b: _abi.Acc) -> _abi.Acc:
+    ai, ad = a.to_arrays()
+    bi, bd = b.to_arrays()
+    return _abi.Acc.from_arrays(ai + bi, ad + bd)
+
+
+def indices_from_acc(acc: _abi.Acc, nb: int, ncomp: int, hours_per_year: float = 8760.0) -> dict:
+    """nsqMain.m:286-301,348-349,366-376 from merged sums (host arithmetic only)."""
+    n = float(acc.n)
+    edns = acc.sum_dns / n
+    plc = acc.n_fail / n
+    ss = max(acc.sum_dns2 - n * edns * edns, 0.0)
+    beta = float(np.sqrt(ss) / n / edns) if edns > 0 else float("inf")
+    return dict(n=int(acc.n), edns=edns, plc=plc, lole=plc * hours_per_year, eens=edns * hours_per_year,
+                beta=beta, mean_iters=acc.sum_iters / n,
+                nodal_eens=np.array(acc.sum_nodal[:nb]) / n,
+                comp_importance=(np.array(acc.comp_fail[:ncomp], dtype=np.float64) / acc.n_fail
+                                 if acc.n_fail else np.zeros(ncomp)))
+
+
+def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, beta_limit: float = 0.0017,
+                        max_samples: int = 100000, batch: int = 100, hours_per_year: float = 8760.0,
+                        rank: int | None = None, world: int | None = None, device=None):
+    """The nsqMain loop (nsqMain.m:208-318) over `world` ranks.
+
+    accumulate_fn(seed, first_index, n) -> _abi.Acc evaluates a scenario range on THIS rank
+    (Engine.nsq_accumulate in production).  Returns (indices dict, merged Acc, history list).
+    """
+    import torch.distributed as dist
+    if rank is None or world is None:
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+        else:
+            rank, world = 0, 1
+    total = _abi.Acc()
+    done, beta, hist = 0, float("inf"), []
+    idx = None
+    while beta > beta_limit and done < max_samples:
+        m = min(batch, max_samples - done)
+        lo, cnt = shard_range(done, m, rank, world)
+        part = accumulate_fn(seed, lo, cnt) if cnt > 0 else _abi.Acc()
+        part = allreduce_acc(part, device)
+        total = merge(total, part)
+        done += m
+        idx = indices_from_acc(total, nb, ncomp, hours_per_year)
+        beta = idx["beta"]
+        hist.append((done, beta, idx["edns"], idx["lole"], idx["plc"]))
+    return idx, total, hist

@@ -1,0 +1,170 @@
+"""GPU parity tests: the HIP path (through the C ABI) against the CPU oracle on the same inputs.
+
+Tolerances (stated here, justified in DESIGN.md "Numerical contract"):
+  * sampled states: bit-exact (integer-threshold Bernoulli on a counter-based RNG);
+  * status, integer accumulators: exact; IPM iteration count: equal, +-1 allowed on <1 % of states
+    (a termination test can sit within rounding of its tolerance);
+  * dns per state: |diff| <= 1e-6 MW (the LP optimum value is unique; MIPS stops at ~1e-7 relative);
+  * nodal split per state: sum over buses == dns to 1e-5 MW, but individual buses only
+    to 5 MW / 0.05 MW on average: the optimal face of this LP is degenerate (all loads cost the same),
+    the interior point's limit on that face is decided by barrier terms that vanish with gamma, so
+    two correct fp64 implementations differ there (the C oracle and the numpy oracle differ by the
+    same amounts; tests/test_oracle.py quantifies it);
+  * aggregated nodal EENS and fp64 sums: relative 2e-3 / 1e-9.
+"""
+import numpy as np
+import pytest
+
+from powersystemsreliabilityassessment_amd import _abi, api
+
+pytestmark = pytest.mark.gpu
+
+DNS_TOL = 1e-6
+
+
+def test_dpp_row_semantics(engine):
+    import ctypes as C
+    rng = np.random.default_rng(0)
+    x = rng.uniform(0.5, 3.0, 64)
+    out = np.zeros(384)
+    rc = engine.L.relmc_dpp_probe(engine._h, x.ctypes.data_as(_abi.c_double_p), out.ctypes.data_as(_abi.c_double_p))
+    assert rc == 0
+    rows = x.reshape(4, 16)
+    assert np.array_equal(out[:64].reshape(4, 16), np.repeat(rows[:, 5:6], 16, axis=1))      # row_newbcast:5
+    np.testing.assert_allclose(out[64:128].reshape(4, 16), np.repeat(rows.sum(1, keepdims=True), 16, 1), rtol=1e-14)
+    assert np.array_equal(out[128:192].reshape(4, 16), np.repeat(rows.max(1, keepdims=True), 16, 1))
+    assert np.array_equal(out[192:256].reshape(4, 16), np.repeat(rows.min(1, keepdims=True), 16, 1))
+    assert np.all(out[256:320] == 65535.0)
+    np.testing.assert_allclose(out[320:384], 1.0 / x, rtol=4e-16)
+    # every lane of a row must hold the bit-identical reduction (row-uniform control flow relies on it)
+    assert np.all(out[64:128].reshape(4, 16) == out[64:128].reshape(4, 16)[:, :1])
+
+
+def test_sampling_bit_exact(engine, oracle):
+    for seed, first, n in ((1, 0, 4096), (7, 123456789012, 1000), (2**40 + 5, 2**33, 257)):
+        a = engine.mc_sampling(None, n, seed=seed, first_index=first)
+        b = oracle.mc_sampling(seed, first, n)
+        assert np.array_equal(a, b)
+    assert engine.mc_sampling(None, 0).shape == (0, engine.case.ncomp)       # empty input
+    assert np.array_equal(engine.thresholds(), oracle.thresholds())
+    assert not engine.mc_sampling(None, 2000, seed=3)[:, 14].any()           # sync condenser forced up
+
+
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_mc_simulation_matches_oracle(engine, oracle, states_fixture, policy):
+    st = states_fixture["matrix"]
+    (dns, nodal, info) = engine.mc_simulation(st, mpopt=api.mpoption(policy), return_info=True)
+    ref = oracle.mc_simulation(st, policy, nthreads=8)
+    assert np.array_equal(info["status"], ref["status"])
+    np.testing.assert_allclose(dns, ref["dns"], rtol=0, atol=DNS_TOL)
+    dit = np.abs(info["iters"] - ref["iters"])
+    assert dit.max() <= 1 and (dit > 0).mean() < 0.01
+    # nodal: conservation is tight, the split only loosely (degenerate optimal face)
+    shed = dns > 0
+    np.testing.assert_allclose(nodal.sum(1)[shed], dns[shed], rtol=0, atol=2e-2)
+    d = np.abs(nodal - ref["nodal"])
+    assert d.max() < 5.0 and d[shed].mean() < 0.05
+    assert np.all(nodal[~shed] == 0)
+    # aggregated over the fixture the split agrees closely
+    tot, tot_ref = nodal.sum(0), ref["nodal"].sum(0)
+    np.testing.assert_allclose(tot, tot_ref, rtol=2e-3, atol=1e-6)
+
+
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_mc_simulation_matches_fixture(engine, states_fixture, policy):
+    """Against the committed vectors: HiGHS LP value (unique optimum) and numpy-MIPS status/iterations."""
+    key = "emulate" if policy == api.REFERENCE_EMULATE else "physical"
+    st = states_fixture["matrix"]
+    dns, nodal, info = engine.mc_simulation(st, mpopt=api.mpoption(policy), return_info=True)
+    exp = [x[key] for x in states_fixture["states"]]
+    np.testing.assert_allclose(dns, [e["dns"] for e in exp], rtol=0, atol=DNS_TOL)
+    np.testing.assert_allclose(dns, [e["highs_dns"] for e in exp], rtol=0, atol=2e-5)
+    assert np.array_equal(info["status"], [e["status"] for e in exp])
+    assert np.abs(info["iters"] - np.array([e["iters"] for e in exp])).max() <= 1
+
+
+def test_single_state_signature(engine):
+    """mc_simulation(state[1 x 71]) -> (scalar dns, nodal[24]) like the reference."""
+    st = np.zeros(engine.case.ncomp)
+    dns, nodal = engine.mc_simulation(st, engine.case, None, 33, 38)
+    assert dns == 0.0 and nodal.shape == (24,) and not nodal.any()
+    st[[22, 32]] = 1                       # G23 + G33 out: 750 MW lost, 195 MW short
+    dns, nodal = engine.mc_simulation(st)
+    assert abs(dns - 195.0) < 1e-5 and abs(nodal.sum() - dns) < 1e-2
+    # ragged batch sizes (1..9 scenarios: partial wavefronts)
+    many = np.tile(st.astype(np.uint8), (9, 1))
+    for n in range(1, 10):
+        d, _ = engine.mc_simulation(many[:n])
+        assert d.shape == (n,) and np.all(np.abs(d - 195.0) < 1e-5)
+
+
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_accumulate_matches_oracle(engine, oracle, policy):
+    n, seed, first = 40000, 11, 5000
+    acc = engine.nsq_accumulate(seed, first, n, api.mpoption(policy))
+    ref = oracle.nsq_accumulate(seed, first, n, policy)
+    ai, ad = acc.to_arrays()
+    ri, rd = ref.to_arrays()
+    assert ai[0] == n
+    assert np.array_equal(ai[:5], ri[:5])                  # n, n_fail, n_singular, n_infeasible, n_nonconverged
+    assert abs(int(ai[5]) - int(ri[5])) <= n // 200        # sum_iters (+-1 on <1 % of states)
+    assert np.array_equal(ai[6:], ri[6:])                  # comp_fail
+    np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8)  # sum dns, sum dns^2
+    np.testing.assert_allclose(ad[2:], rd[2:], rtol=2e-3, atol=1e-3)   # nodal sums
+
+
+def test_partition_invariance(engine):
+    """N-way split of the index range == 1-way run (what multi-GPU sharding relies on)."""
+    from powersystemsreliabilityassessment_amd import dist
+    n, seed = 30000, 5
+    whole = engine.nsq_accumulate(seed, 0, n)
+    for world in (2, 3, 8):
+        merged = _abi.Acc()
+        for r in range(world):
+            lo, cnt = dist.shard_range(0, n, r, world)
+            merged = dist.merge(merged, engine.nsq_accumulate(seed, lo, cnt))
+        wi, wd = whole.to_arrays()
+        mi, md = merged.to_arrays()
+        assert np.array_equal(wi, mi)
+        np.testing.assert_allclose(md, wd, rtol=1e-11, atol=1e-9)
+
+
+def test_nsqmain_reference_defaults_vs_fixture(engine, nsq_fixture):
+    """nsqMain with the reference's own limits (1e5 samples) against the Python restatement of its
+    database-form estimators on the same sampled states (tests/golden/nsq_seed1_1e5.json)."""
+    for key, pol in (("emulate", api.REFERENCE_EMULATE), ("physical", api.PHYSICAL)):
+        r = engine.nsqMain(beta_limit=0.0017, max_iterations=100000, samples_per_batch=10000, seed=1,
+                           mpopt=api.mpoption(pol))
+        e = nsq_fixture[key]
+        assert r.current_iteration == 100000 and not r.converged
+        assert abs(r.accumulated_edns - e["edns"]) < 1e-7
+        assert abs(r.plc - e["plc"]) < 1e-12 and abs(r.accumulated_lole - e["lole"]) < 1e-8
+        assert abs(r.current_beta - e["beta"]) < 1e-9
+        np.testing.assert_allclose(r.nodal_eens, e["nodal_eens"], rtol=5e-3, atol=1e-4)
+        np.testing.assert_allclose(r.comp_importance, e["comp_importance"], rtol=0, atol=1e-12)
+        assert r.n_singular == e["n_singular"]
+        assert len(r.beta_history) == 10 and r.beta_history[-1] == r.current_beta
+
+
+def test_full_size_properties(engine, golden):
+    """BASELINE config 2 (1e6 samples) through size-independent properties + the reference's golden run."""
+    n = 1_000_000
+    acc = engine.nsq_accumulate(1, 0, n)
+    ix = engine.indices(acc)
+    assert acc.n == n and acc.n_nonconverged == 0
+    nodal = np.array(ix.nodal_eens[:24])
+    # conservation: sum of nodal EENS == EDNS (filters at 1e-3 MW per bus lose < 1e-4 MW)
+    assert abs(nodal.sum() - ix.edns) < 1e-3
+    # load buses only
+    assert np.all(nodal[engine.case.bus_pd == 0] == 0)
+    # HL2 >= HL1 copper sheet: PLC at least P(capacity < load) and EDNS >= HL1 EDNS (exact COPT values)
+    assert ix.plc >= 0.084578 - 4 * 0.0003 and ix.edns >= 14.6937 - 4 * 0.07
+    # statistical parity with the reference's golden run (N=1e5, beta=1.45 %): within 3 sigma of its own CoV
+    g = golden["accumulated_edns"]
+    assert abs(ix.edns - g) < 3 * 0.0145 * g + 3 * ix.beta * ix.edns
+    assert abs(ix.lole - golden["accumulated_lole"]) < 3 * 8760 * np.sqrt(0.084 * 0.916 / 1e5) + 10
+    # expected converged values of the REFERENCE_EMULATE policy
+    assert 14.9 < ix.edns < 15.5 and 0.0835 < ix.plc < 0.0860
+    # weak-point statistic that identifies the reference's isolated-bus artifact: importance(L11) ~ 0.004
+    assert 0.003 < ix.comp_importance[33 + 10] < 0.005
+    assert 12.0 < ix.mean_iters < 12.5
