@@ -1,0 +1,153 @@
+#!/usr/bin/env python3
+"""bench.py — headline benchmark of the hot path: Monte Carlo DC-OPF scenarios/sec, IEEE RTS-24.
+
+  python bench.py --gpus N --steps K --warmup W
+  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py)
+
+A "step" is one pass of the fused hot path (sample -> DC-OPF interior point -> accumulate) over one
+batch of `--batch` (default 1e6 = BASELINE.json configs[1]) synthetic scenarios PER GPU, followed
+by the convergence check's all-reduce of the index accumulators when N > 1 (weak scaling: the
+per-GPU batch is fixed).  Scenarios are generated in-kernel by the counter-based sampler, so there
+is no input to stage: the timed region starts with everything it needs resident in HBM (the case
+tables, ~5 KB).  Prints ONE JSON line on rank 0.
+"""
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = matrix peak: 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz
+FLOP_PER_ITER = 40.5e3          # algorithmic flops of one reduced (order 47) Newton step
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=5)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--batch", type=int, default=1_000_000, help="scenarios per GPU per step")
+    ap.add_argument("--seed", type=int, default=1)
+    ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample", type=int, default=0, help="scenarios of the CPU baseline sample (0 = auto)")
+    args = ap.parse_args()
+
+    import torch
+    import torch.distributed as dist
+    from powersystemsreliabilityassessment_amd import api, case24, dist as rdist
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    if not torch.cuda.is_available():
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    torch.cuda.set_device(local_rank)
+    device = torch.device("cuda", local_rank)
+    if world > 1:
+        dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+
+    case = case24.rts24()
+    eng = api.Engine(case, device=local_rank)
+    policy = api.REFERENCE_EMULATE if args.policy == "emulate" else api.PHYSICAL
+    opts = api.mpoption(policy)
+    B = args.batch
+
+    def step(k):
+        # global scenario index space: step k, rank r owns [ (k*world + r)*B, +B )
+        acc = eng.nsq_accumulate(args.seed, (k * world + rank) * B, B, opts)
+        ms = eng.last_kernel_ms()
+        acc = rdist.allreduce_acc(acc, device)       # the convergence check's single all-reduce
+        return acc, ms
+
+    def sync():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    total = None
+    kernel_ms = []
+    for k in range(args.steps):
+        acc, ms = step(args.warmup + k)
+        kernel_ms.append(ms)
+        total = acc if total is None else rdist.merge(total, acc)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+
+    if rank == 0:
+        n_total = int(total.n)
+        idx = rdist.indices_from_acc(total, case.nb, case.ncomp)
+        value = n_total / elapsed
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) * 1e-3
+        flop_per_scen = idx["mean_iters"] * FLOP_PER_ITER
+        achieved = B * flop_per_scen / avg_kernel_s / 1e12          # per GPU, dominant kernel
+        out = {
+            "metric": "Monte Carlo DC-OPF scenarios/sec (RTS-24 HL2 non-sequential)",
+            "value": value, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": "HL2 non-sequential MCS, IEEE RTS-24 DC-OPF load shedding, "
+                                   f"{B:d} samples per GPU per step (BASELINE configs[1])",
+                       "scenarios_per_step_per_gpu": B, "policy": args.policy, "seed": args.seed,
+                       "parallelism": f"scenario-index sharding x{world}, 1 all-reduce of relmc_acc per step"},
+            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "kernel": "relmc_eval_kernel<true,false>", "kernel_ms_avg": avg_kernel_s * 1e3,
+                         "algorithmic_flop_per_scenario": flop_per_scen, "mean_ipm_iterations": idx["mean_iters"]},
+            "indices": {"n": n_total, "edns_mw": idx["edns"], "lole_h_per_yr": idx["lole"], "plc": idx["plc"],
+                        "beta": idx["beta"], "n_singular": int(total.n_singular),
+                        "n_nonconverged": int(total.n_nonconverged)},
+        }
+        # wall-time to EENS CoV < 1 % (second half of BASELINE.json's metric), single GPU loop of nsqMain
+        if world == 1:
+            t1 = time.perf_counter()
+            r = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000,
+                            seed=args.seed, mpopt=opts)
+            out["time_to_cov_1pct"] = {"seconds": time.perf_counter() - t1, "samples": r.current_iteration,
+                                       "beta": r.current_beta, "edns_mw": r.accumulated_edns,
+                                       "batch": 100_000, "converged": r.converged}
+        if world == 1 and not args.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def cpu_baseline(case, policy, seed, n_sample):
+    """The CPU restatement (oracle/relmc_oracle.c: MATPOWER formulation, dense LU KKT solve) timed on
+    the host cores of this box on a bounded sample of the same scenario stream.  Reported baseline
+    only — never the thing measured as `value`."""
+    from oracle import coracle
+    orc = coracle.Oracle(case)
+    cores = orc.max_threads()
+    t0 = time.perf_counter()
+    orc.nsq_accumulate(seed, 0, 200 * cores, policy, nthreads=cores, memo=False)     # calibration
+    rate = 200 * cores / (time.perf_counter() - t0)
+    n = n_sample or int(max(2000, min(2_000_000, rate * 15.0)))                      # ~15 s of CPU work
+    t0 = time.perf_counter()
+    acc = orc.nsq_accumulate(seed, 0, n, policy, nthreads=cores, memo=False)
+    dt = time.perf_counter() - t0
+    return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port",
+            "sample": f"first {n} scenarios of the same seed, every scenario solved (no state memo), "
+                      f"{dt:.1f} s on {cores} OpenMP threads",
+            "edns_mw": acc.sum_dns / acc.n}
+
+
+if __name__ == "__main__":
+    main()

@@ -1,0 +1,138 @@
+"""CPU tests of the host logic and of the C-ABI library (load + exports; no compute without a GPU)."""
+import ctypes as C
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+
+from powersystemsreliabilityassessment_amd import _abi, _lib, dist as rdist
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_library_exports_every_declared_symbol():
+    hdr = open(os.path.join(ROOT, "include", "relmc.h")).read()
+    declared = set(re.findall(r"\b(relmc_[a-z0-9_]+)\s*\(", hdr))
+    assert declared == set(_lib.EXPORTS)
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()
+    L = _lib.load()
+    for s in declared:
+        assert hasattr(L, s), s
+    assert b"gfx950" in L.relmc_version()
+
+
+def test_struct_layouts_and_defaults():
+    L = _lib.load()
+    o = _abi.SolverOpts()
+    L.relmc_solver_opts_default(C.byref(o))
+    d = _abi.default_solver_opts()
+    for f, _ in _abi.SolverOpts._fields_:
+        assert getattr(o, f) == getattr(d, f), f
+    assert (o.max_it, o.feastol, o.xi, o.sigma) == (150, 5e-6, 0.99995, 0.1)
+    n = _abi.NsqOpts()
+    L.relmc_nsq_opts_default(C.byref(n))
+    assert (n.beta_limit, n.max_samples, n.batch, n.hours_per_year) == (0.0017, 100000, 100, 8760.0)   # nsqMain.m:60-62
+
+
+def test_no_device_fails_loudly():
+    """Without a GPU every entry point must fail (no CPU fallback); with one, bad arguments must."""
+    L = _lib.load()
+    h = C.c_void_p()
+    rc = L.relmc_ctx_create(0, C.byref(h))
+    if rc != 0:
+        assert rc == -2 and not h.value            # RELMC_ERR_NO_DEVICE
+        from powersystemsreliabilityassessment_amd import api
+        with pytest.raises(api.RelmcError):
+            api.Engine()
+    else:
+        acc = _abi.Acc()
+        assert L.relmc_nsq_accumulate(h, 1, 0, 10, None, C.byref(acc)) == -5      # RELMC_ERR_NO_CASE
+        L.relmc_ctx_destroy(h)
+    assert L.relmc_ctx_create(0, None) == -1
+
+
+def test_estimators_host_arithmetic(oracle):
+    """relmc_nsq_indices / relmc_acc_merge (product, host only) == the oracle's restatement."""
+    L = _lib.load()
+    a = oracle.nsq_accumulate(3, 0, 20000, 0)
+    b = oracle.nsq_accumulate(3, 20000, 15000, 0)
+    m = _abi.Acc()
+    L.relmc_acc_zero(C.byref(m)); L.relmc_acc_merge(C.byref(m), C.byref(a)); L.relmc_acc_merge(C.byref(m), C.byref(b))
+    whole = oracle.nsq_accumulate(3, 0, 35000, 0)
+    mi, md = m.to_arrays(); wi, wd = whole.to_arrays()
+    assert np.array_equal(mi, wi) and np.allclose(md, wd, rtol=1e-12)
+    out = _abi.Indices()
+    L.relmc_nsq_indices(C.byref(m), 24, 71, 8760.0, C.byref(out))
+    ref = oracle.indices(m)
+    for f in ("n", "edns", "lole", "plc", "beta", "eens", "mean_iters"):
+        assert getattr(out, f) == getattr(ref, f), f
+    assert list(out.nodal_eens) == list(ref.nodal_eens) and list(out.comp_importance) == list(ref.comp_importance)
+    d = rdist.indices_from_acc(m, 24, 71)
+    assert d["edns"] == pytest.approx(out.edns) and d["beta"] == pytest.approx(out.beta) and d["lole"] == pytest.approx(out.lole)
+    # empty accumulator: no NaNs (nsqMain.m:299-301 would divide by zero; SURVEY Appendix E guard)
+    z = _abi.Acc(); L.relmc_nsq_indices(C.byref(z), 24, 71, 8760.0, C.byref(out))
+    assert out.n == 0 and out.edns == 0
+
+
+def test_shard_range_partitions_exactly():
+    for start, count, world in ((0, 10, 3), (5, 1_000_003, 8), (7, 3, 8), (0, 0, 2)):
+        cover = []
+        for r in range(world):
+            lo, cnt = rdist.shard_range(start, count, r, world)
+            cover.extend(range(lo, lo + cnt)) if count < 100 else cover.append((lo, cnt))
+        if count < 100:
+            assert cover == list(range(start, start + count))
+        else:
+            assert cover[0][0] == start and sum(c for _, c in cover) == count
+            assert all(cover[i][0] + cover[i][1] == cover[i + 1][0] for i in range(world - 1))
+
+
+def test_acc_array_roundtrip():
+    a = _abi.Acc(n=5, n_fail=2, sum_dns=3.5, sum_dns2=9.25)
+    a.comp_fail[70] = 4; a.sum_nodal[23] = 1.25
+    i, d = a.to_arrays()
+    b = _abi.Acc.from_arrays(i, d)
+    assert (b.n, b.n_fail, b.sum_dns, b.sum_dns2, b.comp_fail[70], b.sum_nodal[23]) == (5, 2, 3.5, 9.25, 4, 1.25)
+
+
+_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch.distributed as dist
+from powersystemsreliabilityassessment_amd import case24, dist as rdist
+from oracle import coracle
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+case = case24.rts24(); orc = coracle.Oracle(case)
+fn = lambda seed, first, n: orc.nsq_accumulate(seed, first, n, 0, nthreads=2)     # stand-in evaluator (oracle)
+idx, total, hist = rdist.nsq_run_distributed(fn, case.nb, case.ncomp, seed=9, beta_limit=0.02, max_samples=60000, batch=7000)
+if rank == 0:
+    ti, td = total.to_arrays()
+    np.savez(sys.argv[4], ti=ti, td=td, edns=idx["edns"], beta=idx["beta"], n=idx["n"], ncheck=len(hist))
+dist.destroy_process_group()
+"""
+
+
+def test_distributed_driver_gloo_world2(tmp_path, oracle):
+    """N > 1 path on CPU: 2 ranks over gloo, oracle as the per-rank evaluator; the merged accumulators
+    must equal the single-process run over the same global index range (integers exactly)."""
+    script = tmp_path / "worker.py"
+    script.write_text(_WORKER.format(root=ROOT))
+    out = tmp_path / "rank0.npz"
+    port = str(29600 + os.getpid() % 300)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=600) == 0
+    got = np.load(out)
+    n = int(got["n"])
+    assert n % 7000 == 0 and 0 < n <= 63000 and int(got["ncheck"]) == n // 7000
+    single = oracle.nsq_accumulate(9, 0, n, 0)
+    si, sd = single.to_arrays()
+    assert np.array_equal(got["ti"], si)
+    np.testing.assert_allclose(got["td"], sd, rtol=1e-11, atol=1e-9)
+    assert float(got["beta"]) <= 0.02 or n >= 60000
