@@ -1,0 +1,150 @@
+# RelMC.jl — Julia host layer over the C ABI of include/relmc.h (north-star: "host code in Julia
+# calling HIP through a thin C-ABI/ccall layer").  Keeps the reference's call surface:
+#   mc_sampling(U, n, Ng, Nl)                     (Montecarlo_nsq_single/mc_sampling.m:2)
+#   mc_simulation(state, TestSystem, mpopt, Ng, Nl) (mc_simulation.m:1)
+#   nsqMain(; ...)                                (nsqMain.m:208-406)
+# NOTE: Julia is not installed in the build image nor on the GPU box, so this file is NOT executed
+# by the repository's tests; the Python mirror (powersystemsreliabilityassessment_amd/api.py) is.
+module RelMC
+
+const LIB = joinpath(@__DIR__, "..", "powersystemsreliabilityassessment_amd", "csrc", "librelmc.so")
+const MAX_BUS = 128
+const MAX_COMP = 256
+
+struct CaseDesc
+    base_mva::Cdouble
+    nb::Int32; ng::Int32; nl::Int32; nd::Int32; ref_bus::Int32
+    bus_pd::Ptr{Cdouble}
+    inj_bus::Ptr{Int32}
+    inj_pmin::Ptr{Cdouble}; inj_pmax::Ptr{Cdouble}; inj_cost::Ptr{Cdouble}
+    br_from::Ptr{Int32}; br_to::Ptr{Int32}
+    br_b::Ptr{Cdouble}; br_rate::Ptr{Cdouble}
+    unavail::Ptr{Cdouble}
+    always_up::Ptr{UInt8}
+    total_load::Cdouble
+end
+
+mutable struct SolverOpts
+    singular_policy::Int32; max_it::Int32
+    feastol::Cdouble; gradtol::Cdouble; comptol::Cdouble; costtol::Cdouble
+    xi::Cdouble; sigma::Cdouble; z0::Cdouble; alpha_min::Cdouble; max_stepsize::Cdouble
+    SolverOpts() = new()
+end
+
+mutable struct Acc
+    n::Int64; n_fail::Int64; n_singular::Int64; n_infeasible::Int64; n_nonconverged::Int64; sum_iters::Int64
+    comp_fail::NTuple{MAX_COMP,Int64}
+    sum_dns::Cdouble; sum_dns2::Cdouble
+    sum_nodal::NTuple{MAX_BUS,Cdouble}
+    Acc() = new()
+end
+
+mutable struct Indices
+    n::Int64
+    edns::Cdouble; lole::Cdouble; plc::Cdouble; beta::Cdouble; eens::Cdouble; mean_iters::Cdouble
+    nodal_eens::NTuple{MAX_BUS,Cdouble}
+    comp_importance::NTuple{MAX_COMP,Cdouble}
+    Indices() = new()
+end
+
+"TestSystem after the load model of nsqMain.m:121-153 (0-based indices inside)."
+struct TestSystem
+    base_mva::Float64; nb::Int; ng::Int; nl::Int; nd::Int; ref_bus::Int
+    bus_pd::Vector{Float64}
+    inj_bus::Vector{Int32}; inj_pmin::Vector{Float64}; inj_pmax::Vector{Float64}; inj_cost::Vector{Float64}
+    br_from::Vector{Int32}; br_to::Vector{Int32}; br_b::Vector{Float64}; br_rate::Vector{Float64}
+    unavail::Vector{Float64}; always_up::Vector{UInt8}
+    load::Float64                     # TestSystem.load, nsqMain.m:125
+end
+
+mutable struct Engine
+    h::Ptr{Cvoid}
+    sys::TestSystem
+end
+
+check(rc, h, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:relmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
+
+function Engine(sys::TestSystem; device::Integer=0)
+    h = Ref{Ptr{Cvoid}}(C_NULL)
+    rc = ccall((:relmc_ctx_create, LIB), Int32, (Int32, Ref{Ptr{Cvoid}}), device, h)
+    rc == 0 || error("relmc_ctx_create failed ($rc): no usable HIP device (there is no CPU fallback)")
+    eng = Engine(h[], sys)
+    GC.@preserve sys begin
+        d = CaseDesc(sys.base_mva, sys.nb, sys.ng, sys.nl, sys.nd, sys.ref_bus, pointer(sys.bus_pd),
+                     pointer(sys.inj_bus), pointer(sys.inj_pmin), pointer(sys.inj_pmax), pointer(sys.inj_cost),
+                     pointer(sys.br_from), pointer(sys.br_to), pointer(sys.br_b), pointer(sys.br_rate),
+                     pointer(sys.unavail), pointer(sys.always_up), sys.load)
+        check(ccall((:relmc_case_load, LIB), Int32, (Ptr{Cvoid}, Ref{CaseDesc}), eng.h, Ref(d)), eng.h, "relmc_case_load")
+    end
+    finalizer(e -> ccall((:relmc_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h), eng)
+    return eng
+end
+
+"mpoption('PF_DC',1,...,'OPF_ALG_DC',200,'OPF_FLOW_LIM',1) of nsqMain.m:185-186 = MIPS defaults."
+function mpoption(; singular_policy::Integer=0)
+    o = SolverOpts()
+    ccall((:relmc_solver_opts_default, LIB), Cvoid, (Ref{SolverOpts},), o)
+    o.singular_policy = singular_policy
+    return o
+end
+
+"eqstatus = mc_sampling(failure_probabilities, num_samples, numGenerators, numLines): n x (Ng+Nl), 1 = failed."
+function mc_sampling(eng::Engine, failure_probabilities, num_samples::Integer, numGenerators::Integer, numLines::Integer;
+                     seed::Integer=1, first_index::Integer=0)
+    @assert numGenerators == eng.sys.ng && numLines == eng.sys.nl
+    @assert failure_probabilities === nothing || failure_probabilities == eng.sys.unavail
+    ncomp = numGenerators + numLines
+    out = Matrix{UInt8}(undef, ncomp, num_samples)          # column-major: one scenario per column = row-major n x ncomp
+    check(ccall((:relmc_mc_sampling, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int64, Ptr{UInt8}),
+                eng.h, seed, first_index, num_samples, out), eng.h, "relmc_mc_sampling")
+    return permutedims(out)
+end
+
+"[dns, nodal_dns] = mc_simulation(component_states, TestSystem, mpopt, numGenerators, numLines); states: n x (Ng+Nl)."
+function mc_simulation(eng::Engine, component_states::AbstractMatrix, mpopt::SolverOpts=mpoption(),
+                       numGenerators::Integer=eng.sys.ng, numLines::Integer=eng.sys.nl)
+    n = size(component_states, 1)
+    st = Matrix{UInt8}(permutedims(component_states .!= 0))
+    dns = Vector{Float64}(undef, n); nodal = Matrix{Float64}(undef, eng.sys.nb, n)
+    status = Vector{Int32}(undef, n); iters = Vector{Int32}(undef, n)
+    check(ccall((:relmc_mc_simulation, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{UInt8}, Int64, Ref{SolverOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
+                eng.h, st, n, mpopt, dns, nodal, status, iters), eng.h, "relmc_mc_simulation")
+    return dns, permutedims(nodal), status, iters
+end
+
+"One pass of the nsqMain loop body over global scenarios [first_index, first_index+n): additive accumulators."
+function nsq_accumulate(eng::Engine, seed::Integer, first_index::Integer, n::Integer, mpopt::SolverOpts=mpoption())
+    acc = Acc()
+    check(ccall((:relmc_nsq_accumulate, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int64, Ref{SolverOpts}, Ref{Acc}),
+                eng.h, seed, first_index, n, mpopt, acc), eng.h, "relmc_nsq_accumulate")
+    return acc
+end
+
+function indices(eng::Engine, acc::Acc; hours_per_year=8760.0)
+    out = Indices()
+    ccall((:relmc_nsq_indices, LIB), Cvoid, (Ref{Acc}, Int32, Int32, Cdouble, Ref{Indices}),
+          acc, eng.sys.nb, eng.sys.ng + eng.sys.nl, hours_per_year, out)
+    return out
+end
+
+"nsqMain: `while beta > beta_limit && n < max_iterations` (nsqMain.m:208-318) + post-processing (:345-376)."
+function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption())
+    total = Acc(); ccall((:relmc_acc_zero, LIB), Cvoid, (Ref{Acc},), total)
+    done = 0; beta = Inf; idx = Indices()
+    beta_history = Float64[]; edns_history = Float64[]
+    while beta > beta_limit && done < max_iterations
+        m = min(samples_per_batch, max_iterations - done)
+        part = nsq_accumulate(eng, seed, done, m, mpopt)
+        ccall((:relmc_acc_merge, LIB), Cvoid, (Ref{Acc}, Ref{Acc}), total, part)
+        done += m
+        idx = indices(eng, total); beta = idx.beta
+        push!(beta_history, idx.beta); push!(edns_history, idx.edns)
+    end
+    nb = eng.sys.nb; nc = eng.sys.ng + eng.sys.nl
+    return (accumulated_edns=idx.edns, accumulated_lole=idx.lole, plc=idx.plc, current_beta=idx.beta,
+            current_iteration=done, nodal_eens=collect(idx.nodal_eens[1:nb]),
+            comp_importance=collect(idx.comp_importance[1:nc]), beta_history=beta_history, edns_history=edns_history)
+end
+
+end # module
