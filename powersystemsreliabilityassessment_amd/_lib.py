@@ -13,7 +13,7 @@ import subprocess
 from . import _abi
 
 _CSRC = os.path.join(os.path.dirname(os.path.abspath(__file__)), "csrc")
-LIB_PATH = os.path.join(_CSRC, "librelmc.so")
+LIB_PATH = os.environ.get("RELMC_LIB_PATH") or os.path.join(_CSRC, "librelmc.so")   # override: profiling builds only
 
 # every symbol include/relmc.h declares (checked at load time and by tests/test_abi.py)
 EXPORTS = [

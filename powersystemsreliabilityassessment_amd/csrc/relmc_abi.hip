@@ -196,13 +196,50 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     // very end (internal 15), so that a fixed angle is always eliminated last in its island.
     int ext2int[NBT];
     {
-        int pos = 0;
+        // min-fill elimination order on the bus graph (all lines in service = superset of every outage
+        // state), reference bus forced last; records the symbolic fill of the 2x2-block factorisation
+        bool A[NBT][NBT];
+        for (int i = 0; i < NBT; ++i) for (int c = 0; c < NBT; ++c) A[i][c] = false;
+        for (int l = 0; l < nl; ++l) {
+            const int f = d->br_from[l], t = d->br_to[l];
+            if (f < 0 || f >= nb || t < 0 || t >= nb || f == t)
+                return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad branch end points");
+            A[f][t] = A[t][f] = true;
+        }
+        bool gone[NBT] = {false};
+        int order[NBT]; uint32_t hi_ext[NBT];
+        for (int step = 0; step < nb; ++step) {
+            int best = -1; long bestkey = 0;
+            for (int b = 0; b < nb; ++b) {
+                if (gone[b] || (b == d->ref_bus && step < nb - 1)) continue;
+                int deg = 0, fillc = 0;
+                for (int x = 0; x < nb; ++x) if (!gone[x] && x != b && A[b][x]) {
+                    deg++;
+                    for (int y = x + 1; y < nb; ++y) if (!gone[y] && y != b && A[b][y] && !A[x][y]) fillc++;
+                }
+                const long key = (long)fillc * 10000 + deg * 100 + b;
+                if (best < 0 || key < bestkey) { best = b; bestkey = key; }
+            }
+            uint32_t m = 0;
+            for (int x = 0; x < nb; ++x) if (!gone[x] && x != best && A[best][x]) {
+                m |= 1u << x;
+                for (int y = 0; y < nb; ++y) if (!gone[y] && y != best && y != x && A[best][y]) A[x][y] = A[y][x] = true;
+            }
+            gone[best] = true; order[step] = best; hi_ext[best] = m;
+        }
+        // sequence position k -> internal tile id (gen_elim.py SEQ = 16..23, 0..15); reference bus at the end
         for (int i = 0; i < NBT; ++i) { C.b_ext[i] = 0xff; C.b_int[i] = 0xff; }
-        for (int e = 0; e < nb; ++e) {
-            const int k = e == d->ref_bus ? NBT - 1 : pos++;
+        for (int step = 0; step < nb; ++step) {
+            const int e = order[step];
+            const int k = step == nb - 1 ? NBT - 1 : step;
             const int ii = k < 8 ? 16 + k : k - 8;
             ext2int[e] = ii; C.b_ext[ii] = (uint8_t)e; C.b_int[e] = (uint8_t)ii;
             C.exist_mask |= 1u << ii;
+        }
+        for (int e = 0; e < nb; ++e) {
+            uint32_t m = 0;
+            for (int x = 0; x < nb; ++x) if ((hi_ext[e] >> x) & 1u) m |= 1u << ext2int[x];
+            C.fill[ext2int[e]] = m;
         }
     }
     C.ref_bus = ext2int[d->ref_bus];

@@ -52,6 +52,8 @@ struct DevCase {
     uint8_t b_ext[NBT];             // internal tile position -> external bus number
     uint8_t b_int[NBT];             // external bus number -> internal tile position
     uint8_t T[NBT][NBT];            // index of K(bus i, bus c) in the value arrays
+    uint32_t fill[NBT];             // symbolic fill: bit j of fill[i] = block (i, j) can be non-zero when bus i is
+                                    // eliminated (j later in the sequence); superset over all outage states
     uint32_t thr[NCOMPMAX];         // Bernoulli thresholds floor(U*2^32)
 };
 

@@ -114,6 +114,12 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
 #define TROW(s) ((s) == 1 ? &C.T[s1bus][0] : &C.T[rlane][0])
 #define ARR_A(s) ((s) == 0 ? S.Mcomb : ((s) == 2 ? S.Bcomb : (s1lam ? S.Bcomb : S.Mcomb)))
 #define ARR_B(s) ((s) == 0 ? S.Bswap : ((s) == 2 ? S.Ecomb : (s1lam ? S.Ecomb : S.Bswap)))
+    // symbolic fill masks of the block elimination, wave-uniform (SGPRs): guards of gen_elim.py
+#define RELMC_FM(i) const uint32_t fmask_##i = __builtin_amdgcn_readfirstlane(C.fill[i]);
+    RELMC_FM(0) RELMC_FM(1) RELMC_FM(2) RELMC_FM(3) RELMC_FM(4) RELMC_FM(5) RELMC_FM(6) RELMC_FM(7)
+    RELMC_FM(8) RELMC_FM(9) RELMC_FM(10) RELMC_FM(11) RELMC_FM(12) RELMC_FM(13) RELMC_FM(14) RELMC_FM(15)
+    RELMC_FM(16) RELMC_FM(17) RELMC_FM(18) RELMC_FM(19) RELMC_FM(20) RELMC_FM(21) RELMC_FM(22) RELMC_FM(23)
+#define FILLMASK(i) fmask_##i
 
     // ---- accumulators (nsqMain.m:282-301 in per-sample form) ---------------------------
     double acc_dns = 0.0, acc_dns2 = 0.0, acc_shed[IS] = {0.0, 0.0, 0.0, 0.0};
@@ -237,9 +243,8 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                             if (!__any(ch)) break;
                         }
                         // rule 1: the island's angle reference is its bus that is eliminated last
-                        // (sequence 16..23, 0..15; the host numbers the reference bus 15 and keeps the
-                        // external order otherwise, so this is the reference bus or the island's
-                        // highest-numbered bus)
+                        // (sequence = internal buses 16..23, 0..15 = the host's min-fill order with the
+                        // reference bus at the very end, internal 15)
                         const uint32_t Rlo = R & 0xffffu;
                         const int pin = 31 - __clz((int)(Rlo ? Rlo : R));
                         // island rules 2-5 (DESIGN.md "island policy")
@@ -466,7 +471,12 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                 const double compcond = zmu / (1.0 + mx_x);
                 const double costcond = __builtin_fabs(fval - f0) / (1.0 + __builtin_fabs(f0));
                 const bool conv = it > 0 && feascond < a.feastol && gradcond < a.gradtol && compcond < a.comptol && costcond < a.costtol;
+#ifdef RELMC_ABLATE_FIXIT
+                if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }
+                else if (false) {}
+#else
                 if (conv) { status = 0; iterating = false; }
+#endif
                 else if (it > 0 && (xnan || alphap < a.alpha_min || alphad < a.alpha_min || gamma < eps || gamma > 1.0 / eps)) {
 #ifdef RELMC_DEBUG_STATUS
                     status = xnan ? 10 : alphap < a.alpha_min ? 11 : alphad < a.alpha_min ? 12 : gamma < eps ? 13 : 14;
@@ -481,9 +491,22 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                 f0 = fval;
                 it += 1;
                 // ---- Newton step: assemble, eliminate, back-substitute (all in VGPRs) -----------
+#ifndef RELMC_ABLATE_NO_ASSEMBLE
                 RELMC_K_ASSEMBLE
+#else
+                { double seed_ = S.Mcomb[DIAG0 + rlane];
+#define RELMC_SEEDK(sv, cv) K_##sv##_##cv = seed_ + cv;
+                  RELMC_K_FOREACH(RELMC_SEEDK) }
+#endif
+#ifndef RELMC_ABLATE_NO_ELIM
                 RELMC_K_ELIMINATE
                 RELMC_K_BACKSUB
+#else
+                { double acc_ = 0.0;
+#define RELMC_SUMK(sv, cv) acc_ += K_##sv##_##cv;
+                  RELMC_K_FOREACH(RELMC_SUMK)
+                  SOL_0 = RHS_0 * 1e-3 + acc_ * 1e-30; SOL_1 = RHS_1 * 1e-3; SOL_2 = RHS_2 * 1e-3; }
+#endif
                 S.sol[rlane] = SOL_0; S.sol[16 + rlane] = SOL_1; S.sol[32 + rlane] = SOL_2;
                 double step2 = SOL_0 * SOL_0 + SOL_1 * SOL_1 + SOL_2 * SOL_2;
                 double rp = DINF, rd = DINF;
