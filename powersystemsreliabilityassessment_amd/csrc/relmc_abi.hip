@@ -11,6 +11,8 @@
 #include <new>
 #include <string>
 #include <vector>
+#include <algorithm>
+#include <cstddef>
 
 #include "../../include/relmc.h"
 #include "relmc_kernels.hip"
@@ -31,6 +33,7 @@ struct relmc_ctx {
     DevAcc* dacc = nullptr;
     int num_cu = 0;
     int blocks_per_cu = 0;
+    uint32_t scen_doubles = 0, lds_bytes = 0;
     double last_kernel_ms = 0.0;
     std::string err;
 };
@@ -64,7 +67,7 @@ EvalArgs make_args(const relmc_solver_opts& o)
 
 int grid_for(relmc_ctx* ctx, int64_t n)
 {
-    const int64_t groups = (n + 3) / 4;
+    const int64_t groups = ((n + 3) / 4 + WPB - 1) / WPB;
     int64_t g = (int64_t)ctx->num_cu * ctx->blocks_per_cu;
     if (g > groups) g = groups;
     if (g < 1) g = 1;
@@ -76,7 +79,7 @@ int ensure_partial(relmc_ctx* ctx, int blocks)
     if (blocks <= ctx->partial_blocks) return RELMC_OK;
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
     ctx->dpartial = nullptr; ctx->partial_blocks = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->dpartial, sizeof(Partial) * 64 * (size_t)blocks));
+    HIP_TRY(ctx, hipMalloc(&ctx->dpartial, sizeof(Partial) * 64 * WPB * (size_t)blocks));
     ctx->partial_blocks = blocks;
     return RELMC_OK;
 }
@@ -88,8 +91,9 @@ int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
     int rc = ensure_partial(ctx, blocks);
     if (rc) return rc;
     a.partial = ctx->dpartial;
+    a.scen_doubles = ctx->scen_doubles;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64), 0, ctx->stream, ctx->dcase, a);
+    hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     *blocks_out = blocks;
@@ -109,7 +113,7 @@ int finish_timing(relmc_ctx* ctx)
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.1 (gfx950; 16-lane DPP-row IPM, KKT in VGPRs)"; }
+const char* relmc_version(void) { return "relmc 0.2 (gfx950; 16-lane DPP-row IPM, sparse 2x2-block LDL' in LDS, static schedule)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
@@ -132,9 +136,7 @@ int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
         return RELMC_ERR_NO_DEVICE;
     }
     ctx->num_cu = prop.multiProcessorCount;
-    int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<true, false>, 64, 0) != hipSuccess || bpc < 1) bpc = 4;
-    ctx->blocks_per_cu = bpc;
+    ctx->blocks_per_cu = 1;
     *out = ctx;
     return RELMC_OK;
 }
@@ -173,8 +175,10 @@ void relmc_nsq_opts_default(relmc_nsq_opts* o)
     relmc_solver_opts_default(&o->solver);
 }
 
-// Build the device tables (tile padding, pair map, incidence lists, thresholds) from the plain
-// case description.  Mirrors what nsqMain.m:42-167 prepares once before its Monte Carlo loop.
+// Build the device tables from the plain case description: internal bus numbering = elimination
+// order of the sparse block LDL' (level-then-min-fill, reference bus last), symbolic fill, the
+// static task schedule the kernel interprets, incidence lists, thresholds.  Mirrors what
+// nsqMain.m:42-167 prepares once before its Monte Carlo loop.
 int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
 {
     if (!ctx) return RELMC_ERR_INVALID;
@@ -186,100 +190,165 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
     if (nb > NBT || nl > NLT || ninj > NIT || ncomp > NCOMPMAX)
         return fail(ctx, RELMC_ERR_UNSUPPORTED,
-                    "relmc_case_load: case exceeds the compiled tile (24 buses, 48 lines, 64 injections)");
+                    "relmc_case_load: case exceeds the compiled tile (32 buses, 48 lines, 64 injections)");
     DevCase& C = ctx->hcase;
     std::memset(&C, 0, sizeof(C));
     C.nb = nb; C.ng = ng; C.nl = nl; C.nd = nd; C.ninj = ninj; C.ncomp = ncomp;
     C.base_mva = d->base_mva; C.total_load = d->total_load;
-    // Internal bus numbering = position in the elimination sequence (gen_elim.py: internal buses
-    // 16..23 first, then 0..15): external buses in increasing order, the reference bus moved to the
-    // very end (internal 15), so that a fixed angle is always eliminated last in its island.
-    int ext2int[NBT];
-    {
-        // min-fill elimination order on the bus graph (all lines in service = superset of every outage
-        // state), reference bus forced last; records the symbolic fill of the 2x2-block factorisation
-        bool A[NBT][NBT];
-        for (int i = 0; i < NBT; ++i) for (int c = 0; c < NBT; ++c) A[i][c] = false;
-        for (int l = 0; l < nl; ++l) {
-            const int f = d->br_from[l], t = d->br_to[l];
-            if (f < 0 || f >= nb || t < 0 || t >= nb || f == t)
-                return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad branch end points");
-            A[f][t] = A[t][f] = true;
-        }
-        bool gone[NBT] = {false};
-        int order[NBT]; uint32_t hi_ext[NBT];
-        for (int step = 0; step < nb; ++step) {
-            int best = -1; long bestkey = 0;
-            for (int b = 0; b < nb; ++b) {
-                if (gone[b] || (b == d->ref_bus && step < nb - 1)) continue;
-                int deg = 0, fillc = 0;
-                for (int x = 0; x < nb; ++x) if (!gone[x] && x != b && A[b][x]) {
-                    deg++;
-                    for (int y = x + 1; y < nb; ++y) if (!gone[y] && y != b && A[b][y] && !A[x][y]) fillc++;
-                }
-                const long key = (long)fillc * 10000 + deg * 100 + b;
-                if (best < 0 || key < bestkey) { best = b; bestkey = key; }
+    C.exist_mask = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+
+    // ---- elimination order on the bus graph (all lines in service = superset of every outage state)
+    std::vector<std::vector<char>> A(nb, std::vector<char>(nb, 0));
+    for (int l = 0; l < nl; ++l) {
+        const int f = d->br_from[l], t = d->br_to[l];
+        if (f < 0 || f >= nb || t < 0 || t >= nb || f == t || !(d->br_b[l] == d->br_b[l]))
+            return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad branch end points");
+        A[f][t] = A[t][f] = 1;
+    }
+    std::vector<int> ext2int(nb, -1), level(nb, -1);
+    std::vector<char> gone(nb, 0);
+    std::vector<std::vector<int>> hi_ext(nb);          // higher neighbours (external ids) at elimination time
+    for (int step = 0; step < nb; ++step) {
+        int best = -1; long bestkey = 0;
+        for (int b = 0; b < nb; ++b) {
+            if (gone[b] || (b == d->ref_bus && step < nb - 1)) continue;
+            int deg = 0, fillc = 0, lev = 0;
+            for (int x = 0; x < nb; ++x) {
+                if (x == b || !A[b][x]) continue;
+                if (gone[x]) { if (level[x] + 1 > lev) lev = level[x] + 1; continue; }
+                deg++;
+                for (int y = x + 1; y < nb; ++y) if (!gone[y] && y != b && A[b][y] && !A[x][y]) fillc++;
             }
-            uint32_t m = 0;
-            for (int x = 0; x < nb; ++x) if (!gone[x] && x != best && A[best][x]) {
-                m |= 1u << x;
-                for (int y = 0; y < nb; ++y) if (!gone[y] && y != best && y != x && A[best][y]) A[x][y] = A[y][x] = true;
+            // shallow elimination tree first (fewer dependent passes), then little fill
+            const long key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + b;
+            if (best < 0 || key < bestkey) { best = b; bestkey = key; }
+        }
+        int lev = 0;
+        for (int x = 0; x < nb; ++x) if (x != best && A[best][x] && gone[x] && level[x] + 1 > lev) lev = level[x] + 1;
+        level[best] = lev;
+        for (int x = 0; x < nb; ++x) if (!gone[x] && x != best && A[best][x]) {
+            hi_ext[best].push_back(x);
+            for (int y = 0; y < nb; ++y) if (!gone[y] && y != best && y != x && A[best][y]) A[x][y] = A[y][x] = 1;
+        }
+        gone[best] = 1;
+        ext2int[best] = step;
+    }
+    for (int i = 0; i < NBT; ++i) { C.b_ext[i] = 0xff; C.b_int[i] = 0xff; C.b_vinj[i] = -1; }
+    for (int e = 0; e < nb; ++e) { C.b_ext[ext2int[e]] = (uint8_t)e; C.b_int[e] = (uint8_t)ext2int[e]; }
+    C.ref_bus = ext2int[d->ref_bus];                    // == nb - 1
+    std::vector<std::vector<int>> N(nb);                // higher neighbours, internal ids, ascending
+    for (int e = 0; e < nb; ++e) {
+        for (int x : hi_ext[e]) N[ext2int[e]].push_back(ext2int[x]);
+        std::sort(N[ext2int[e]].begin(), N[ext2int[e]].end());
+    }
+
+    // ---- block storage: diagonal blocks, off-diagonal blocks (a, i) a > i, rhs blocks, P blocks
+    std::vector<std::vector<int>> blk(nb, std::vector<int>(nb, -1));
+    int noff = 0;
+    for (int i = 0; i < nb; ++i) for (int a : N[i]) blk[a][i] = nb + noff++;
+    if (noff > MAXOFF) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: too much fill for the solver workspace");
+    C.noff = noff;
+    C.off_rhs = (uint16_t)(4 * (nb + noff));
+    C.off_p = (uint16_t)(C.off_rhs + 4 * nb);
+    C.nws = (uint32_t)C.off_p + 4u * nb;
+    auto OFFD = [&](int i) { return 4 * i; };
+    auto OFFB = [&](int a, int i) { return 4 * blk[a][i]; };
+    auto OFFY = [&](int i) { return (int)C.off_rhs + 4 * i; };
+    auto OFFP = [&](int i) { return (int)C.off_p + 4 * i; };
+
+    // ---- task list in sequential (right-looking) order, then list scheduling into passes of 16
+    struct Task { uint8_t kind; uint16_t o[4]; std::vector<int> rd, wr; };
+    std::vector<Task> tasks;
+    auto unit = [](int off) { return off >> 2; };       // dependency unit = one 2x2 block
+    for (int i = 0; i < nb; ++i) {
+        for (size_t ia = 0; ia < N[i].size(); ++ia)
+            for (size_t ib = 0; ib <= ia; ++ib) {
+                const int a2 = N[i][ia], b2 = N[i][ib];
+                const int T = a2 == b2 ? OFFD(a2) : OFFB(a2, b2);
+                if (a2 != b2 && blk[a2][b2] < 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: symbolic factorisation inconsistent");
+                Task t; t.kind = 0; t.o[0] = (uint16_t)T; t.o[1] = (uint16_t)OFFB(a2, i); t.o[2] = (uint16_t)OFFB(b2, i); t.o[3] = (uint16_t)OFFD(i);
+                t.rd = {unit(OFFB(a2, i)), unit(OFFB(b2, i)), unit(OFFD(i)), unit(T)}; t.wr = {unit(T)};
+                tasks.push_back(t);
             }
-            gone[best] = true; order[step] = best; hi_ext[best] = m;
-        }
-        // sequence position k -> internal tile id (gen_elim.py SEQ = 16..23, 0..15); reference bus at the end
-        for (int i = 0; i < NBT; ++i) { C.b_ext[i] = 0xff; C.b_int[i] = 0xff; }
-        for (int step = 0; step < nb; ++step) {
-            const int e = order[step];
-            const int k = step == nb - 1 ? NBT - 1 : step;
-            const int ii = k < 8 ? 16 + k : k - 8;
-            ext2int[e] = ii; C.b_ext[ii] = (uint8_t)e; C.b_int[e] = (uint8_t)ii;
-            C.exist_mask |= 1u << ii;
-        }
-        for (int e = 0; e < nb; ++e) {
-            uint32_t m = 0;
-            for (int x = 0; x < nb; ++x) if ((hi_ext[e] >> x) & 1u) m |= 1u << ext2int[x];
-            C.fill[ext2int[e]] = m;
+        for (int a2 : N[i]) {                             // right-hand side as a pseudo-bus: y_a' -= y_i' P W_a'
+            Task t; t.kind = 0; t.o[0] = (uint16_t)OFFY(a2); t.o[1] = (uint16_t)OFFY(i); t.o[2] = (uint16_t)OFFB(a2, i); t.o[3] = (uint16_t)OFFD(i);
+            t.rd = {unit(OFFY(i)), unit(OFFB(a2, i)), unit(OFFD(i)), unit(OFFY(a2))}; t.wr = {unit(OFFY(a2))};
+            tasks.push_back(t);
         }
     }
-    C.ref_bus = ext2int[d->ref_bus];
-    for (int i = 0; i < NBT; ++i) { C.b_vinj[i] = -1; for (int c = 0; c < NBT; ++c) C.T[i][c] = (uint8_t)(i == c ? DIAG0 + i : ZIDX); }
+    for (int i = 0; i < nb; ++i) {
+        Task t; t.kind = 1; t.o[0] = (uint16_t)OFFD(i); t.o[1] = (uint16_t)OFFY(i); t.o[2] = (uint16_t)OFFP(i); t.o[3] = 0;
+        t.rd = {unit(OFFD(i)), unit(OFFY(i))}; t.wr = {unit(OFFP(i)), unit(OFFY(i))};
+        tasks.push_back(t);
+    }
+    for (int a2 = nb - 1; a2 >= 0; --a2)
+        for (int i = 0; i < a2; ++i) {
+            if (blk[a2][i] < 0) continue;
+            Task t; t.kind = 2; t.o[0] = (uint16_t)OFFY(i); t.o[1] = (uint16_t)OFFB(a2, i); t.o[2] = (uint16_t)OFFP(i); t.o[3] = (uint16_t)OFFY(a2);
+            t.rd = {unit(OFFP(i)), unit(OFFB(a2, i)), unit(OFFY(a2)), unit(OFFY(i))}; t.wr = {unit(OFFY(i))};
+            tasks.push_back(t);
+        }
+    {
+        const int nunits = (int)C.nws / 4 + 1;
+        std::vector<int> lastw(nunits, -1), lastr(nunits, -1), pkind, pcount;
+        for (const Task& t : tasks) {
+            int ready = 0;
+            for (int r : t.rd) if (lastw[r] + 1 > ready) ready = lastw[r] + 1;          // RAW
+            for (int w : t.wr) { if (lastw[w] + 1 > ready) ready = lastw[w] + 1;        // WAW
+                                 if (lastr[w] > ready) ready = lastr[w]; }               // WAR (same pass is fine: loads precede stores)
+            int p = -1;
+            for (int q = ready; q < (int)pkind.size(); ++q) if (pkind[q] == t.kind && pcount[q] < ROWL) { p = q; break; }
+            if (p < 0) { pkind.push_back(t.kind); pcount.push_back(0); p = (int)pkind.size() - 1; }
+            if (p >= MAXPASS) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver schedule exceeds MAXPASS");
+            for (int k = 0; k < 4; ++k) C.task[p][pcount[p]][k] = t.o[k];
+            pcount[p]++;
+            for (int r : t.rd) if (p > lastr[r]) lastr[r] = p;
+            for (int w : t.wr) lastw[w] = p;
+        }
+        C.npass = (uint16_t)pkind.size();
+        int nu = 0, ni = 0;
+        for (size_t q = 0; q < pkind.size(); ++q) {
+            C.pass_ntask[q] = (uint8_t)pcount[q];
+            if (pkind[q] == 0) nu++; else if (pkind[q] == 1) ni++;
+            // kinds must appear as contiguous phases UPD.. INV.. BWD..
+            if (q > 0 && pkind[q] < pkind[q - 1]) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: schedule phases out of order");
+        }
+        C.npass_upd = (uint16_t)nu; C.npass_inv = (uint16_t)ni;
+    }
+
+    // ---- lines
     for (int l = 0; l < NLT; ++l) C.l_partner[l] = -1;
-    // lines, bus pairs
-    int pair_of[NBT][NBT];
-    for (int i = 0; i < NBT; ++i) for (int c = 0; c < NBT; ++c) pair_of[i][c] = -1;
-    int npair = 0;
-    std::vector<int> pair_lines(PMAX, 0), pair_owner(PMAX, -1);
+    std::vector<int> pair_owner((size_t)nb * nb, -1), pair_lines((size_t)nb * nb, 0);
+    std::vector<char> has_line(nb + noff, 0);
     for (int l = 0; l < nl; ++l) {
-        if (d->br_from[l] < 0 || d->br_from[l] >= nb || d->br_to[l] < 0 || d->br_to[l] >= nb ||
-            d->br_from[l] == d->br_to[l] || !(d->br_b[l] == d->br_b[l]))
-            return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad branch end points");
         const int f = ext2int[d->br_from[l]], t = ext2int[d->br_to[l]];
-        const int a = f < t ? f : t, b = f < t ? t : f;
+        const int lo = f < t ? f : t, hi = f < t ? t : f;
         uint32_t flags = LF_EXISTS;
         if (d->br_rate[l] != 0.0) flags |= LF_LIMITED;
-        int p = pair_of[a][b];
-        if (p < 0) {
-            if (npair >= PMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 48 distinct bus pairs");
-            p = npair++;
-            pair_of[a][b] = p; pair_owner[p] = l; flags |= LF_OWNER;
-            C.T[a][b] = (uint8_t)p; C.T[b][a] = (uint8_t)(PMAX + p);
+        const size_t key = (size_t)hi * nb + lo;
+        if (pair_owner[key] < 0) {
+            pair_owner[key] = l; flags |= LF_OWNER;
+            if (blk[hi][lo] < 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: line outside the symbolic pattern");
+            C.l_blk[l] = (uint16_t)OFFB(hi, lo);
+            has_line[blk[hi][lo]] = 1;
         } else {
-            if (pair_lines[p] >= 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than two parallel lines");
-            C.l_partner[pair_owner[p]] = l;
+            if (pair_lines[key] >= 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than two parallel lines");
+            C.l_partner[pair_owner[key]] = l;
         }
-        pair_lines[p]++;
+        pair_lines[key]++;
         C.l_b[l] = d->br_b[l];
         C.l_rate[l] = d->br_rate[l] / d->base_mva;
-        C.l_info[l] = (uint32_t)f | ((uint32_t)t << 8) | ((uint32_t)p << 16) | (flags << 24);
+        C.l_info[l] = (uint32_t)f | ((uint32_t)t << 8) | (flags << 24);
         for (int side = 0; side < 2; ++side) {
             const int bus = side ? t : f;
             if (C.b_nline[bus] >= DEGMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 8 lines at a bus");
             C.b_line[bus][C.b_nline[bus]++] = (uint8_t)(l | (side ? 0x80 : 0));
         }
     }
-    C.npair = npair;
-    // injections
+    int nzero = 0;
+    for (int k = nb; k < nb + noff; ++k) if (!has_line[k]) C.zero_off[nzero++] = (uint16_t)(4 * k);
+    C.nzero = (uint16_t)nzero;
+    // ---- injections
     for (int j = 0; j < ninj; ++j) {
         if (d->inj_bus[j] < 0 || d->inj_bus[j] >= nb) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad injection bus");
         const int bus = ext2int[d->inj_bus[j]];
@@ -302,7 +371,19 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         if (t > 4294967295.0) t = 4294967295.0;
         C.thr[k] = d->always_up[k] ? 0u : (uint32_t)t;   // mc_sampling.m:40-41
     }
+    // ---- launch geometry: dynamic LDS = case tables + schedule + one workspace per scenario row
+    uint32_t scen = C.nws + (uint32_t)EVAL_DOUBLES;
+    while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
+    ctx->scen_doubles = scen;
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + (uint32_t)C.npass * (uint32_t)sizeof(C.task[0]);
+    ctx->lds_bytes = ((case_bytes + 15u) & ~15u) + 4u * WPB * scen * (uint32_t)sizeof(double);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
+    if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    int bpc = 0;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<true, false>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
+    ctx->blocks_per_cu = bpc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase, &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     ctx->has_case = true;
@@ -420,7 +501,7 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
         int blocks = 0;
         int rc = launch_eval<true, false>(ctx, a, &blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(1), dim3(256), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks, ctx->dacc);
+        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks * 4 * WPB, ctx->dacc);
         HIP_TRY(ctx, hipGetLastError());
         relmc_acc part;
         HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));

@@ -8,35 +8,46 @@ namespace relmc {
 
 // ---- tile geometry: one scenario = one 16-lane DPP row of a wavefront -----------------
 constexpr int ROWL = 16;           // lanes per scenario
-constexpr int NBT = 24;            // bus tile (KKT order 2*NBT = 48 = 3 row slots x 16 lanes)
-constexpr int KS = 3;              // KKT row slots per lane
-constexpr int LS = 3;              // line slots per lane   (NLT = 48 lines)
-constexpr int IS = 4;              // injection slots/lane  (NIT = 64 injections)
+constexpr int BS = 2;              // bus slots per lane      (NBT = 32 buses)
+constexpr int LS = 3;              // line slots per lane     (NLT = 48 lines)
+constexpr int IS = 4;              // injection slots/lane    (NIT = 64 injections)
+constexpr int NBT = BS * ROWL;
 constexpr int NLT = LS * ROWL;
 constexpr int NIT = IS * ROWL;
-constexpr int PMAX = 48;           // distinct bus pairs joined by >= 1 line
-constexpr int DIAG0 = 2 * PMAX;    // value arrays: [0,PMAX) lower half, [PMAX,2PMAX) upper half,
-constexpr int ZIDX = DIAG0 + NBT;  //               [DIAG0, DIAG0+NBT) diagonal, ZIDX = constant 0
-constexpr int CARR = ZIDX + 1;
 constexpr int DEGMAX = 8;          // lines per bus
 constexpr int BINJMAX = 8;         // injections per bus
 constexpr int NCOMPMAX = 128;      // sampled components (generators + lines)
+constexpr int MAXPASS = 96;        // passes of the static solver schedule
+constexpr int MAXOFF = 160;        // off-diagonal 2x2 blocks of the factor (lines + fill)
 
-// l_info: from | to<<8 | pair<<16 | flags<<24
+// l_info: from | to<<8 | flags<<24   (internal bus numbers = elimination positions)
 constexpr uint32_t LF_EXISTS = 1u, LF_OWNER = 2u, LF_LIMITED = 4u;
 // i_info: bus | kind<<8
 constexpr uint32_t IK_NONE = 0u, IK_REAL = 1u, IK_VIRTUAL = 2u;
 
+// Static solver schedule.  Passes [0, npass_upd) are PK_UPD, then npass_inv PK_INV, then PK_BWD.
+//   PK_UPD  T -= Wa * inv(D) * Wb'         task = (T, Wa, Wb, D)      W offsets of 2x2 blocks
+//   PK_INV  P = inv(D); y <- P * y         task = (D, Y, P, -)
+//   PK_BWD  y_i -= P_i * W' * x_a          task = (Y_i, W, P_i, Y_a)
+//
+// Per-scenario solver workspace W (doubles), 2x2 blocks row-major [tt, tl, lt, ll]:
+//   [0, 4*nb)                 diagonal blocks  D_i = [[M_ii, B_ii], [B_ii, -E_i]]
+//   [4*nb, 4*(nb+noff))       off-diagonal blocks K(a, i), a eliminated after i (lines and fill)
+//   [off_rhs, off_rhs+4*nb)   right-hand side as a pseudo-bus: block i = [[y_theta, y_lambda], [0, 0]]
+//   [off_p, off_p+4*nb)       P_i = inv(D_i) after the factorisation
 struct DevCase {
-    int32_t nb, ng, nl, nd, ninj, ncomp, ref_bus, npair;
+    int32_t nb, ng, nl, nd, ninj, ncomp, ref_bus, noff;
     double base_mva, total_load;
     uint32_t exist_mask;            // bit i = bus i exists
-    uint32_t pad0;
+    uint32_t nws;                   // doubles in W
+    uint16_t off_rhs, off_p;
+    uint16_t npass, npass_upd, npass_inv, nzero;
     // lines
     double l_b[NLT];
     double l_rate[NLT];             // p.u. (0 = unlimited)
     uint32_t l_info[NLT];
     int32_t l_partner[NLT];         // the other line of the same bus pair, -1 if none
+    uint16_t l_blk[NLT];            // owner lines: W offset of the pair's off-diagonal block
     // injections (real generators then virtual generators = loads)
     double i_lo[NIT];               // p.u.
     double i_hi[NIT];               // p.u.
@@ -49,12 +60,13 @@ struct DevCase {
     uint8_t b_ninj[NBT];
     uint8_t b_inj[NBT][BINJMAX];
     int8_t b_vinj[NBT];             // virtual generator at the bus, -1 if none
-    uint8_t b_ext[NBT];             // internal tile position -> external bus number
-    uint8_t b_int[NBT];             // external bus number -> internal tile position
-    uint8_t T[NBT][NBT];            // index of K(bus i, bus c) in the value arrays
-    uint32_t fill[NBT];             // symbolic fill: bit j of fill[i] = block (i, j) can be non-zero when bus i is
-                                    // eliminated (j later in the sequence); superset over all outage states
+    uint8_t b_ext[NBT];             // internal bus -> external bus number
+    uint8_t b_int[NBT];             // external bus number -> internal bus
     uint32_t thr[NCOMPMAX];         // Bernoulli thresholds floor(U*2^32)
+    // static schedule of the sparse block LDL' (computed once per case on the host)
+    uint16_t zero_off[MAXOFF];      // W offsets of fill-only blocks (cleared every iteration)
+    uint8_t pass_ntask[MAXPASS];
+    uint16_t task[MAXPASS][ROWL][4];
 };
 
 // per-lane partial accumulators written once per workgroup-row, reduced by relmc_finalize_kernel
@@ -79,7 +91,8 @@ struct EvalArgs {
     double* nodal;
     int32_t* status;
     int32_t* iters;
-    Partial* partial;               // [gridDim.x * 64]
+    Partial* partial;               // [gridDim.x * blockDim.x]
+    uint32_t scen_doubles;          // per-scenario LDS doubles (W + evaluation arrays), = 2 mod 4
 };
 
 }  // namespace relmc

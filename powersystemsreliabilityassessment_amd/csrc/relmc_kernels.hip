@@ -4,17 +4,18 @@
 // i.e. Bernoulli outage sampling, the MATPOWER DC-OPF load-curtailment LP solved by the MIPS
 // primal-dual interior-point iteration, and the index accumulators.
 //
-// Mapping: ONE SCENARIO PER 16-LANE DPP ROW, four scenarios per wavefront, one
-// wavefront per workgroup.  The reduced symmetric KKT system of an IPM iteration
-//     [ Mth  B' ] [dth ]   [ -Nth            ]      Mth = Bf' diag(mu/z) Bf  (weighted Laplacian)
-//     [ B   -E  ] [dlam] = [ -g - C D^-1 Np  ]      E   = C D^-1 C'          (diagonal)
-// (order 2*nb = 48: generator/load steps dp are eliminated analytically) lives entirely in VGPRs:
-// KKT row rho = 16*slot + lane is held by one lane as 48 + 1 doubles per slot.  Gaussian
-// elimination broadcasts the pivot row with DPP `row_newbcast` (v_mov_b64_dpp), so the
-// n^3/3 update is pure v_fma_f64 at full 64-lane occupancy with no LDS traffic and no
-// cross-lane shuffles through memory.  LDS only carries the sparse per-scenario vectors that
-// need a gather/scatter (line <-> bus <-> injection incidence) and the static case tables.
+// Mapping: ONE SCENARIO PER 16-LANE DPP ROW, four scenarios per wavefront.
+//  * per-scenario vectors (lines, injections, buses) live in registers, one element per
+//    (lane, slot); scalars of the iteration come from DPP row_ror all-reduces;
+//  * the Newton step solves the reduced symmetric KKT system
+//        [ Mth  B' ] [dth ]   [ -Nth            ]     Mth = Bf' diag(mu/z) Bf (weighted Laplacian)
+//        [ B   -E  ] [dlam] = [ -g - C D^-1 Np  ]     E   = C D^-1 C'         (diagonal)
+//    by a SPARSE 2x2-block LDL' (one block per bus pair (theta_i, lambda_i), pivot
+//    det = -(m*e + b^2) free of cancellation) whose symbolic structure, fill and task schedule
+//    are computed once per case on the host: the kernel only interprets a static list of
+//    passes (16 independent block tasks per pass and scenario) on a ~4 KB LDS workspace.
 #include <hip/hip_runtime.h>
+#include <stddef.h>
 #include <stdint.h>
 
 #include "relmc_dev.h"
@@ -23,13 +24,20 @@ namespace relmc {
 
 #define DEVFI __device__ __forceinline__
 
+#ifndef RELMC_WPB
+#define RELMC_WPB 1                 // wavefronts per workgroup (waves never synchronise after the prologue)
+#endif
+constexpr int WPB = RELMC_WPB;
+#ifndef RELMC_MIN_WAVES
+#define RELMC_MIN_WAVES 1          // min waves per SIMD the register allocator must allow
+#endif
+constexpr int EVAL_DOUBLES = 4 * NLT + 3 * NIT;   // Lg, Llx, Lq, LF | Ip, IinvD, INpD
+
 template <int CTRL>
 DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
 template <int CTRL>
 DEVFI uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true); }
 
-// broadcast lane L of every 16-lane row to the whole row
-#define BCAST(L, x) dppd<0x150 + (L)>(x)
 // all-reduce over the 16 lanes of a row (row_ror 8,4,2,1); every lane gets bit-identical results
 DEVFI double row_sum(double v) { v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v); return v; }
 DEVFI double row_max(double v) { v = __builtin_fmax(v, dppd<0x128>(v)); v = __builtin_fmax(v, dppd<0x124>(v)); v = __builtin_fmax(v, dppd<0x122>(v)); v = __builtin_fmax(v, dppd<0x121>(v)); return v; }
@@ -68,35 +76,43 @@ DEVFI bool outbit(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, int k)
     return (w >> (k & 31)) & 1u;
 }
 
-// per-scenario LDS scratch (one per DPP row); 917 doubles = odd stride -> rows land on different banks
-struct ScenLds {
-    double Mcomb[CARR], Bcomb[CARR], Bswap[CARR], Ecomb[CARR];
-    double Lg[NLT], Llx[NLT], Lq[NLT], LF[NLT];
-    double Ip[NIT], IinvD[NIT], INpD[NIT];
-    double sol[2 * NBT];
-    double pad;
-};
-
-#include "elim_nb24.inc"
+struct __attribute__((aligned(16))) d2 { double x, y; };
+DEVFI d2 ld2(const double* p) { return *reinterpret_cast<const d2*>(p); }
+DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinterpret_cast<d2*>(p) = v; }
 
 #define DINF __builtin_inf()
+// compiler-only fence: stops LICM from parking loop-invariant LDS table reads in VGPRs for the whole
+// kernel (registers are the scarce resource here, LDS reads are cheap)
+#define RELOAD_FENCE() __asm__ volatile("" ::: "memory")
+// keeps the unrolled per-slot bodies from being interleaved (each body has ~20 live temporaries)
+#define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 
 template <bool FROM_RNG, bool WRITE_OUT>
-__global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restrict__ gcase, const EvalArgs a)
+__global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCase* __restrict__ gcase, const EvalArgs a)
 {
-    __shared__ DevCase C;
-    __shared__ ScenLds SC[4];
-    const int lane = threadIdx.x, rlane = lane & 15, row = lane >> 4;
+    extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
+    DevCase& C = *reinterpret_cast<DevCase*>(smem);
+    const int tid = threadIdx.x, lane = tid & 63, rlane = lane & 15, row = tid >> 4;
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + (uint32_t)gcase->npass * (uint32_t)sizeof(C.task[0]);
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(gcase);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(&C);
-        for (int i = lane; i < (int)(sizeof(DevCase) / 4); i += 64) dst[i] = src[i];
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        for (uint32_t i = tid; i < case_bytes / 4; i += 64 * WPB) dst[i] = src[i];
     }
-    ScenLds& S = SC[row];
-    for (int i = rlane; i < CARR; i += ROWL) { S.Mcomb[i] = 0.0; S.Bcomb[i] = 0.0; S.Bswap[i] = 0.0; S.Ecomb[i] = 0.0; }
     __syncthreads();
+    const int nws = (int)C.nws;
+    double* const W = reinterpret_cast<double*>(smem + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
+    double* const Lg = W + nws;
+    double* const Llx = Lg + NLT;
+    double* const Lq = Llx + NLT;
+    double* const LF = Lq + NLT;
+    double* const Ip = LF + NLT;
+    double* const IinvD = Ip + NIT;
+    double* const INpD = IinvD + NIT;
+    for (int i = rlane; i < nws; i += ROWL) W[i] = 0.0;      // second rows of the rhs blocks stay 0 forever
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
+    const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero;
     const double base = C.base_mva;
     const double eps = 2.220446049250313e-16;
 
@@ -107,19 +123,6 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
     uint32_t iinfo[IS];
 #pragma unroll
     for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[16 * s + rlane];
-    // KKT rows: slot0 = theta(bus rlane); slot1 = theta(bus 16+rlane) for rlane<8, lambda(bus 8+rlane) else;
-    //           slot2 = lambda(bus rlane)
-    const bool s1lam = rlane >= 8;
-    const int s1bus = 16 + (rlane & 7);
-#define TROW(s) ((s) == 1 ? &C.T[s1bus][0] : &C.T[rlane][0])
-#define ARR_A(s) ((s) == 0 ? S.Mcomb : ((s) == 2 ? S.Bcomb : (s1lam ? S.Bcomb : S.Mcomb)))
-#define ARR_B(s) ((s) == 0 ? S.Bswap : ((s) == 2 ? S.Ecomb : (s1lam ? S.Ecomb : S.Bswap)))
-    // symbolic fill masks of the block elimination, wave-uniform (SGPRs): guards of gen_elim.py
-#define RELMC_FM(i) const uint32_t fmask_##i = __builtin_amdgcn_readfirstlane(C.fill[i]);
-    RELMC_FM(0) RELMC_FM(1) RELMC_FM(2) RELMC_FM(3) RELMC_FM(4) RELMC_FM(5) RELMC_FM(6) RELMC_FM(7)
-    RELMC_FM(8) RELMC_FM(9) RELMC_FM(10) RELMC_FM(11) RELMC_FM(12) RELMC_FM(13) RELMC_FM(14) RELMC_FM(15)
-    RELMC_FM(16) RELMC_FM(17) RELMC_FM(18) RELMC_FM(19) RELMC_FM(20) RELMC_FM(21) RELMC_FM(22) RELMC_FM(23)
-#define FILLMASK(i) fmask_##i
 
     // ---- accumulators (nsqMain.m:282-301 in per-sample form) ---------------------------
     double acc_dns = 0.0, acc_dns2 = 0.0, acc_shed[IS] = {0.0, 0.0, 0.0, 0.0};
@@ -127,25 +130,29 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
     uint32_t acc_cfi[IS] = {0, 0, 0, 0}, acc_cfl[LS] = {0, 0, 0};
 
     const int64_t ngroups = (a.n + 3) >> 2;
-    for (int64_t grp = blockIdx.x; grp < ngroups; grp += gridDim.x) {
-        const int64_t sidx = grp * 4 + row;
+    const int64_t gwave = (int64_t)blockIdx.x * WPB + (tid >> 6);
+    const int64_t gstride = (int64_t)gridDim.x * WPB;
+    for (int64_t grp = gwave; grp < ngroups; grp += gstride) {
+        const int64_t sidx = grp * 4 + (lane >> 4);
         const bool live = sidx < a.n;
+        RELOAD_FENCE();
 
         // per-scenario state ------------------------------------------------------------
         bool l_on[LS], l_act[LS], i_on[IS], i_box[IS];
-        double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS];
+        double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS], cB1[LS], cB2[LS];
         double ip[IS], ilo[IS], ilam[IS], izp[IS], izm[IS], imup[IS], imum[IS];
-        double BV_0 = 0.0, BV_1 = 0.0, BV_2 = 0.0;
-        RELMC_K_DECL
+        double bth[BS], bla[BS], cBd[BS];
         uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, pinned = 0, dropped = 0;
         double gamma = 1.0, fval = 0.0, f0 = 0.0, alphap = 1.0, alphad = 1.0, zmu = 0.0;
         uint32_t niq = 0;
         int it = 0, status = 0;
         bool infeas = false, singular = false, iterating = false;
 #pragma unroll
-        for (int s = 0; s < LS; ++s) { l_on[s] = false; l_act[s] = false; LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; }
+        for (int s = 0; s < LS; ++s) { l_on[s] = false; l_act[s] = false; LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cB1[s] = 0; cB2[s] = 0; }
 #pragma unroll
         for (int s = 0; s < IS; ++s) { i_on[s] = false; i_box[s] = false; ip[s] = 0; ilo[s] = 0; ilam[s] = 0; izp[s] = 1; izm[s] = 1; imup[s] = 1; imum[s] = 1; }
+#pragma unroll
+        for (int t = 0; t < BS; ++t) { bth[t] = 0; bla[t] = 0; cBd[t] = 0; }
 
         if (live) {
             // ===== mc_sampling.m:24-41: Bernoulli outage state (1 = failed) ==================
@@ -198,13 +205,13 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
             }
 
             // ===== topology: adjacency, isolated buses, islands ===============================
-            uint32_t adj0 = 0, adj1 = 0;
+            uint32_t adjm[BS];
             bool iso = false;
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < BS; ++t) {
                 const int i = 16 * t + rlane;
                 uint32_t adj = 0;
-                if (i < NBT && ((C.exist_mask >> i) & 1u)) {
+                if (i < nb) {
                     const int nlb = C.b_nline[i];
                     for (int e = 0; e < nlb; ++e) {
                         const uint32_t ent = C.b_line[i][e];
@@ -216,15 +223,13 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                     }
                     iso = iso || adj == 0;
                 }
-                if (t == 0) adj0 = adj; else adj1 = adj;
+                adjm[t] = adj;
             }
             const uint64_t isob = __ballot(iso);
-            const bool iso_any = ((isob >> (16 * row)) & 0xffffull) != 0;
+            const bool iso_any = ((isob >> (lane & 48)) & 0xffffull) != 0;
             // a bus without any in-service branch makes MATPOWER's KKT matrix exactly singular; the
             // reference consumes the start point (mc_simulation.m:41,54)
             singular = (a.policy == 0) && iso_any;
-            pinned = ~C.exist_mask & 0xffffffu;
-            dropped = pinned;
 
             if (!singular) {
                 uint32_t remaining = C.exist_mask;
@@ -235,18 +240,16 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                         uint32_t R = 1u << (__ffs((int)remaining) - 1);
                         for (int sweep = 0; sweep < NBT; ++sweep) {
                             uint32_t c = 0;
-                            if ((R >> rlane) & 1u) c |= adj0;
-                            if (rlane < 8 && ((R >> (16 + rlane)) & 1u)) c |= adj1;
+#pragma unroll
+                            for (int t = 0; t < BS; ++t) if ((R >> (16 * t + rlane)) & 1u) c |= adjm[t];
                             const uint32_t Rn = R | row_or(c);
                             const bool ch = Rn != R;
                             R = Rn;
                             if (!__any(ch)) break;
                         }
-                        // rule 1: the island's angle reference is its bus that is eliminated last
-                        // (sequence = internal buses 16..23, 0..15 = the host's min-fill order with the
-                        // reference bus at the very end, internal 15)
-                        const uint32_t Rlo = R & 0xffffu;
-                        const int pin = 31 - __clz((int)(Rlo ? Rlo : R));
+                        // rule 1: the island's angle reference is its bus that is eliminated last =
+                        // highest internal number (the host puts the reference bus at nb-1)
+                        const int pin = 31 - __clz((int)R);
                         // island rules 2-5 (DESIGN.md "island policy")
                         uint32_t cnt = 0; double losum = 0.0; bool inI[IS];
 #pragma unroll
@@ -285,35 +288,32 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                 }
             }
 
-            // ===== constant (per scenario) susceptance blocks: Bbus with pins/drops masked ======
+            // ===== constant (per scenario) susceptance entries of the KKT blocks, pins/drops masked ==
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
                 const uint32_t inf = linfo[s];
                 if ((inf >> 24) & LF_OWNER) {
-                    const int f = inf & 0xff, t = (inf >> 8) & 0xff, p = (inf >> 16) & 0xff;
+                    const int f = inf & 0xff, t = (inf >> 8) & 0xff;
                     double v = l_on[s] ? lb[s] : 0.0;
                     const int pr = lpart[s];
                     if (pr >= 0 && !outbit(o0, o1, o2, o3, ng + pr)) v += C.l_b[pr];
                     v = -v;
-                    const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;
-                    const double vlo = (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) ? 0.0 : v;   // (row lam_lo, col th_hi)
-                    const double vhi = (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) ? 0.0 : v;   // (row lam_hi, col th_lo)
-                    S.Bcomb[p] = vlo; S.Bcomb[PMAX + p] = vhi;
-                    S.Bswap[p] = vhi; S.Bswap[PMAX + p] = vlo;
+                    const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;    // block (hi, lo): rows of hi, columns of lo
+                    cB1[s] = (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) ? 0.0 : v;   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
+                    cB2[s] = (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) ? 0.0 : v;   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
                 }
             }
 #pragma unroll
-            for (int t = 0; t < 2; ++t) {
+            for (int t = 0; t < BS; ++t) {
                 const int i = 16 * t + rlane;
-                if (i < NBT) {
+                if (i < nb) {
                     double d = 0.0;
                     const int nlb = C.b_nline[i];
                     for (int e = 0; e < nlb; ++e) {
                         const int l = C.b_line[i][e] & 0x7f;
                         if (!outbit(o0, o1, o2, o3, ng + l)) d += C.l_b[l];
                     }
-                    if (((pinned | dropped) >> i) & 1u) d = 0.0;
-                    S.Bcomb[DIAG0 + i] = d; S.Bswap[DIAG0 + i] = d;
+                    cBd[t] = (((pinned | dropped) >> i) & 1u) ? 0.0 : d;
                 }
             }
 
@@ -356,10 +356,12 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
 
         // ===== mips main loop =======================================
         while (__any(iterating)) {
+            RELOAD_FENCE();
             if (iterating) {
                 // ---- evaluate h, Lx, barrier terms; scatter to LDS; convergence norms -------------
                 double mx_gh = -DINF, mx_x = 0.0, mx_z = 0.0, mx_lx = 0.0, mx_lammu = 0.0;
                 bool nanx = false;
+                double gown[LS];
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     const int l = 16 * s + rlane;
@@ -378,7 +380,9 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(lmup[s], lmum[s]));
                         }
                     }
-                    S.Lg[l] = g; S.Llx[l] = lx; S.Lq[l] = lx + q; S.LF[l] = LFv[s];
+                    gown[s] = g;
+                    Lg[l] = g; Llx[l] = lx; Lq[l] = lx + q; LF[l] = LFv[s];
+                    SLOT_FENCE();
                 }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
@@ -401,71 +405,72 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(imup[s], imum[s]));
                         }
                     }
-                    S.Ip[j] = pv; S.IinvD[j] = invD; S.INpD[j] = npd;
+                    Ip[j] = pv; IinvD[j] = invD; INpD[j] = npd;
+                    SLOT_FENCE();
                 }
-                // weighted-Laplacian off-diagonals (pair owners), pinned columns removed
+                // off-diagonal KKT blocks of the line pairs (weighted Laplacian entry + constant B entries)
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     const uint32_t inf = linfo[s];
                     if ((inf >> 24) & LF_OWNER) {
-                        const int l = 16 * s + rlane, f = inf & 0xff, t = (inf >> 8) & 0xff, p = (inf >> 16) & 0xff;
-                        double gs = S.Lg[l];
-                        if (lpart[s] >= 0) gs += S.Lg[lpart[s]];
+                        const int l = 16 * s + rlane, f = inf & 0xff, t = (inf >> 8) & 0xff;
+                        double gs = gown[s];
+                        if (lpart[s] >= 0) gs += Lg[lpart[s]];
                         const double v = (((pinned >> f) | (pinned >> t)) & 1u) ? 0.0 : -gs;
-                        S.Mcomb[p] = v; S.Mcomb[PMAX + p] = v;
+                        double* blk = W + C.l_blk[l];
+                        st2(blk, v, cB1[s]); st2(blk + 2, cB2[s], 0.0);
                     }
                 }
-                // bus gathers -> KKT diagonals and right-hand sides
-                auto theta_eval = [&](const int bi, const double bv, double& rhs) {
-                    double md = 0.0, lx = 0.0, nq_ = 0.0;
-                    const int nlb = C.b_nline[bi];
-                    for (int e = 0; e < nlb; ++e) {
-                        const uint32_t ent = C.b_line[bi][e];
-                        const int l = ent & 0x7f;
-                        const double sg = (ent & 0x80) ? -1.0 : 1.0;
-                        md += S.Lg[l];
-                        lx = __builtin_fma(sg, S.Llx[l], lx);
-                        nq_ = __builtin_fma(sg, S.Lq[l], nq_);
+                for (int z = rlane; z < nzero; z += ROWL) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
+                // bus gathers -> diagonal KKT blocks and right-hand sides
+#pragma unroll
+                for (int t = 0; t < BS; ++t) {
+                    const int bi = 16 * t + rlane;
+                    if (bi < nb) {
+                        double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
+                        const int nlb = C.b_nline[bi];
+                        for (int e = 0; e < nlb; ++e) {
+                            const uint32_t ent = C.b_line[bi][e];
+                            const int l = ent & 0x7f;
+                            const double sg = (ent & 0x80) ? -1.0 : 1.0;
+                            md += Lg[l];
+                            lx = __builtin_fma(sg, Llx[l], lx);
+                            nq_ = __builtin_fma(sg, Lq[l], nq_);
+                            bal = __builtin_fma(sg, LF[l], bal);
+                        }
+                        const int nib = C.b_ninj[bi];
+                        for (int e = 0; e < nib; ++e) {
+                            const int j = C.b_inj[bi][e];
+                            bal -= Ip[j]; E += IinvD[j]; ssum += INpD[j];
+                        }
+                        double d00, d11, r0, r1;
+                        if ((pinned >> bi) & 1u) {        // fixed angle: identity row; its multiplier is -lx
+                            d00 = 1.0; r0 = 0.0;
+                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(lx));
+                        } else {
+                            d00 = md; r0 = -nq_;
+                            mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lx));
+                        }
+                        if ((dropped >> bi) & 1u) {       // dependent balance row
+                            d11 = -1.0; r1 = 0.0;
+                        } else {
+                            d11 = -E; r1 = -bal - ssum;
+                            mx_gh = __builtin_fmax(mx_gh, __builtin_fabs(bal));
+                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(bla[t]));
+                        }
+                        mx_x = __builtin_fmax(mx_x, __builtin_fabs(bth[t]));
+                        nanx = nanx || bth[t] != bth[t];
+                        st2(W + 4 * bi, d00, cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11);
+                        st2(W + off_rhs + 4 * bi, r0, r1);
                     }
-                    if ((pinned >> bi) & 1u) {        // fixed angle: identity row; its multiplier is -lx
-                        S.Mcomb[DIAG0 + bi] = 1.0; rhs = 0.0;
-                        mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(lx));
-                    } else {
-                        S.Mcomb[DIAG0 + bi] = md; rhs = -nq_;
-                        mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lx));
-                    }
-                    mx_x = __builtin_fmax(mx_x, __builtin_fabs(bv));
-                    nanx = nanx || bv != bv;
-                };
-                auto lambda_eval = [&](const int bi, const double bv, double& rhs) {
-                    double bal = 0.0, E = 0.0, ssum = 0.0;
-                    const int nlb = C.b_nline[bi];
-                    for (int e = 0; e < nlb; ++e) {
-                        const uint32_t ent = C.b_line[bi][e];
-                        bal = __builtin_fma((ent & 0x80) ? -1.0 : 1.0, S.LF[ent & 0x7f], bal);
-                    }
-                    const int nib = C.b_ninj[bi];
-                    for (int e = 0; e < nib; ++e) {
-                        const int j = C.b_inj[bi][e];
-                        bal -= S.Ip[j]; E += S.IinvD[j]; ssum += S.INpD[j];
-                    }
-                    if ((dropped >> bi) & 1u) {       // dependent / non-existent balance row
-                        S.Ecomb[DIAG0 + bi] = -1.0; rhs = 0.0;
-                    } else {
-                        S.Ecomb[DIAG0 + bi] = -E; rhs = -bal - ssum;
-                        mx_gh = __builtin_fmax(mx_gh, __builtin_fabs(bal));
-                        mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(bv));
-                    }
-                };
-                theta_eval(rlane, BV_0, RHS_0);
-                if (!s1lam) theta_eval(s1bus, BV_1, RHS_1); else lambda_eval(s1bus, BV_1, RHS_1);
-                lambda_eval(rlane, BV_2, RHS_2);
+                    SLOT_FENCE();
+                }
 
                 // ---- convergence test (mips.m feascond/gradcond/compcond/costcond) --------------
                 mx_gh = row_max(mx_gh); mx_x = row_max(mx_x); mx_z = row_max(mx_z);
                 mx_lx = row_max(mx_lx); mx_lammu = row_max(mx_lammu);
                 const uint64_t nanb = __ballot(nanx);
-                const bool xnan = ((nanb >> (16 * row)) & 0xffffull) != 0;
+                const bool xnan = ((nanb >> (lane & 48)) & 0xffffull) != 0;
                 const double feascond = mx_gh / (1.0 + __builtin_fmax(mx_x, mx_z));
                 const double gradcond = mx_lx / (1.0 + mx_lammu);
                 const double compcond = zmu / (1.0 + mx_x);
@@ -477,95 +482,127 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
 #else
                 if (conv) { status = 0; iterating = false; }
 #endif
-                else if (it > 0 && (xnan || alphap < a.alpha_min || alphad < a.alpha_min || gamma < eps || gamma > 1.0 / eps)) {
-#ifdef RELMC_DEBUG_STATUS
-                    status = xnan ? 10 : alphap < a.alpha_min ? 11 : alphad < a.alpha_min ? 12 : gamma < eps ? 13 : 14;
-#else
-                    status = 2;
-#endif
-                    iterating = false;
-                }
+                else if (it > 0 && (xnan || alphap < a.alpha_min || alphad < a.alpha_min || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
             }
+            RELOAD_FENCE();
             if (iterating) {
                 f0 = fval;
                 it += 1;
-                // ---- Newton step: assemble, eliminate, back-substitute (all in VGPRs) -----------
-#ifndef RELMC_ABLATE_NO_ASSEMBLE
-                RELMC_K_ASSEMBLE
-#else
-                { double seed_ = S.Mcomb[DIAG0 + rlane];
-#define RELMC_SEEDK(sv, cv) K_##sv##_##cv = seed_ + cv;
-                  RELMC_K_FOREACH(RELMC_SEEDK) }
-#endif
-#ifndef RELMC_ABLATE_NO_ELIM
-                RELMC_K_ELIMINATE
-                RELMC_K_BACKSUB
-#else
-                { double acc_ = 0.0;
-#define RELMC_SUMK(sv, cv) acc_ += K_##sv##_##cv;
-                  RELMC_K_FOREACH(RELMC_SUMK)
-                  SOL_0 = RHS_0 * 1e-3 + acc_ * 1e-30; SOL_1 = RHS_1 * 1e-3; SOL_2 = RHS_2 * 1e-3; }
-#endif
-                S.sol[rlane] = SOL_0; S.sol[16 + rlane] = SOL_1; S.sol[32 + rlane] = SOL_2;
-                double step2 = SOL_0 * SOL_0 + SOL_1 * SOL_1 + SOL_2 * SOL_2;
-                double rp = DINF, rd = DINF;
-                double dF[LS], dG[LS], ldzp[LS], ldzm[LS], ldmup[LS], ldmum[LS];
-#pragma unroll
-                for (int s = 0; s < LS; ++s) {
-                    dF[s] = 0; dG[s] = 0; ldzp[s] = 0; ldzm[s] = 0; ldmup[s] = 0; ldmum[s] = 0;
-                    if (l_on[s]) {
-                        const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
-                        const int lf = f < 16 ? 32 + f : f + 8, lt = t < 16 ? 32 + t : t + 8;
-                        dF[s] = lb[s] * (S.sol[f] - S.sol[t]);
-                        dG[s] = lb[s] * (S.sol[lf] - S.sol[lt]);
-                        if (l_act[s]) {
-                            const double hp = LFv[s] - lr[s], hm = -LFv[s] - lr[s];
-                            const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
-                            ldzp[s] = -hp - lzp[s] - dF[s];
-                            ldzm[s] = -hm - lzm[s] + dF[s];
-                            ldmup[s] = -lmup[s] + (gamma - lmup[s] * ldzp[s]) * rzp;
-                            ldmum[s] = -lmum[s] + (gamma - lmum[s] * ldzm[s]) * rzm;
-                            if (ldzp[s] < 0.0) rp = __builtin_fmin(rp, lzp[s] * frcp(-ldzp[s]));
-                            if (ldzm[s] < 0.0) rp = __builtin_fmin(rp, lzm[s] * frcp(-ldzm[s]));
-                            if (ldmup[s] < 0.0) rd = __builtin_fmin(rd, lmup[s] * frcp(-ldmup[s]));
-                            if (ldmum[s] < 0.0) rd = __builtin_fmin(rd, lmum[s] * frcp(-ldmum[s]));
-                        }
+#ifndef RELMC_ABLATE_NO_SOLVE
+                // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
+                for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'
+                    if (rlane < C.pass_ntask[p]) {
+                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                        double* T = W + (dsc.x & 0xffffu);
+                        const double* Wa = W + (dsc.x >> 16);
+                        const double* Wb = W + (dsc.y & 0xffffu);
+                        const double* D = W + (dsc.y >> 16);
+                        const d2 dA = ld2(D), dB = ld2(D + 2);
+                        const d2 a0 = ld2(Wa), a1 = ld2(Wa + 2), b0 = ld2(Wb), b1 = ld2(Wb + 2);
+                        d2 t0 = ld2(T), t1 = ld2(T + 2);
+                        const double pm = dA.x, pb = dA.y, pe = -dB.y;
+                        const double q = frcp(__builtin_fma(pm, pe, pb * pb));
+                        const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
+                        const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
+                        const double g10 = __builtin_fma(a1.x, P00, a1.y * P01), g11 = __builtin_fma(a1.x, P01, a1.y * P11);
+                        t0.x -= __builtin_fma(g00, b0.x, g01 * b0.y); t0.y -= __builtin_fma(g00, b1.x, g01 * b1.y);
+                        t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
+                        st2(T, t0.x, t0.y); st2(T + 2, t1.x, t1.y);
                     }
                 }
-                double dpv[IS], dlb[IS], idzp[IS], idzm[IS], idmup[IS], idmum[IS];
+                for (int p = npu; p < npu + npi; ++p) {      // P = inv(D); y <- P*y
+                    if (rlane < C.pass_ntask[p]) {
+                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                        const double* D = W + (dsc.x & 0xffffu);
+                        double* Y = W + (dsc.x >> 16);
+                        double* P = W + (dsc.y & 0xffffu);
+                        const d2 dA = ld2(D), dB = ld2(D + 2), y = ld2(Y);
+                        const double pm = dA.x, pb = dA.y, pe = -dB.y;
+                        const double q = frcp(__builtin_fma(pm, pe, pb * pb));
+                        const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
+                        st2(P, P00, P01); st2(P + 2, P01, P11);
+                        st2(Y, __builtin_fma(P00, y.x, P01 * y.y), __builtin_fma(P01, y.x, P11 * y.y));
+                    }
+                }
+                for (int p = npu + npi; p < npass; ++p) {    // y_i -= P_i * W' * x_a
+                    if (rlane < C.pass_ntask[p]) {
+                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                        double* Yi = W + (dsc.x & 0xffffu);
+                        const double* Wk = W + (dsc.x >> 16);
+                        const double* P = W + (dsc.y & 0xffffu);
+                        const double* Ya = W + (dsc.y >> 16);
+                        const d2 w0 = ld2(Wk), w1 = ld2(Wk + 2), p0 = ld2(P), p1 = ld2(P + 2), x = ld2(Ya);
+                        d2 y = ld2(Yi);
+                        const double u0 = __builtin_fma(w0.x, x.x, w1.x * x.y), u1 = __builtin_fma(w0.y, x.x, w1.y * x.y);
+                        y.x -= __builtin_fma(p0.x, u0, p0.y * u1); y.y -= __builtin_fma(p1.x, u0, p1.y * u1);
+                        st2(Yi, y.x, y.y);
+                    }
+                }
+#endif
+                RELOAD_FENCE();
+                // ---- step lengths ---------------------------------------------------------------------
+                const double* X = W + off_rhs;               // solution: block i = [dtheta_i, dlambda_i, 0, 0]
+                double step2 = 0.0;
+                double dth[BS], dla[BS];
+#pragma unroll
+                for (int t = 0; t < BS; ++t) {
+                    const int bi = 16 * t + rlane;
+                    dth[t] = 0; dla[t] = 0;
+                    if (bi < nb) { const d2 x = ld2(X + 4 * bi); dth[t] = x.x; dla[t] = x.y; step2 = __builtin_fma(x.x, x.x, __builtin_fma(x.y, x.y, step2)); }
+                }
+                // Two passes over the slack/multiplier steps: pass 1 only finds the step lengths (ratio
+                // tests), pass 2 recomputes dz, dmu and applies them.  Recomputing ~150 VALU instructions
+                // keeps 72 VGPRs free, which is what lets two wavefronts share a SIMD.
+                double rp = DINF, rd = DINF;
+                double dF[LS], dG[LS];
+#pragma unroll
+                for (int s = 0; s < LS; ++s) {
+                    dF[s] = 0; dG[s] = 0;
+                    if (l_on[s]) {
+                        const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                        const d2 xf = ld2(X + 4 * f), xt = ld2(X + 4 * t);
+                        dF[s] = lb[s] * (xf.x - xt.x);
+                        dG[s] = lb[s] * (xf.y - xt.y);
+                        if (l_act[s]) {
+                            const double hp = LFv[s] - lr[s], hm = -LFv[s] - lr[s];
+                            const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
+                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
+                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
+                            if (dzp < 0.0) rp = __builtin_fmin(rp, lzp[s] * frcp(-dzp));
+                            if (dzm < 0.0) rp = __builtin_fmin(rp, lzm[s] * frcp(-dzm));
+                            if (dmup < 0.0) rd = __builtin_fmin(rd, lmup[s] * frcp(-dmup));
+                            if (dmum < 0.0) rd = __builtin_fmin(rd, lmum[s] * frcp(-dmum));
+                        }
+                    }
+                    SLOT_FENCE();
+                }
+                double dpv[IS], dlb[IS];
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = 16 * s + rlane;
-                    dpv[s] = 0; dlb[s] = 0; idzp[s] = 0; idzm[s] = 0; idmup[s] = 0; idmum[s] = 0;
+                    dpv[s] = 0; dlb[s] = 0;
                     if (i_on[s]) {
-                        const int bi = iinfo[s] & 0xff;
-                        dlb[s] = S.sol[bi < 16 ? 32 + bi : bi + 8];
+                        dlb[s] = X[4 * (iinfo[s] & 0xff) + 1];
                         if (i_box[s]) {
-                            dpv[s] = __builtin_fma(dlb[s], S.IinvD[j], -S.INpD[j]);   // dp = (-Np + dlam)/D
+                            dpv[s] = __builtin_fma(dlb[s], IinvD[j], -INpD[j]);   // dp = (-Np + dlam)/D
                             const double hp = ip[s] - C.i_hi[j], hm = ilo[s] - ip[s];
-                            const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
-                            idzp[s] = -hp - izp[s] - dpv[s];
-                            idzm[s] = -hm - izm[s] + dpv[s];
-                            idmup[s] = -imup[s] + (gamma - imup[s] * idzp[s]) * rzp;
-                            idmum[s] = -imum[s] + (gamma - imum[s] * idzm[s]) * rzm;
-                            if (idzp[s] < 0.0) rp = __builtin_fmin(rp, izp[s] * frcp(-idzp[s]));
-                            if (idzm[s] < 0.0) rp = __builtin_fmin(rp, izm[s] * frcp(-idzm[s]));
-                            if (idmup[s] < 0.0) rd = __builtin_fmin(rd, imup[s] * frcp(-idmup[s]));
-                            if (idmum[s] < 0.0) rd = __builtin_fmin(rd, imum[s] * frcp(-idmum[s]));
+                            const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
+                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
+                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
+                            if (dzp < 0.0) rp = __builtin_fmin(rp, izp[s] * frcp(-dzp));
+                            if (dzm < 0.0) rp = __builtin_fmin(rp, izm[s] * frcp(-dzm));
+                            if (dmup < 0.0) rd = __builtin_fmin(rd, imup[s] * frcp(-dmup));
+                            if (dmum < 0.0) rd = __builtin_fmin(rd, imum[s] * frcp(-dmum));
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
+                    SLOT_FENCE();
                 }
                 step2 = row_sum(step2);
                 if (!(step2 <= a.max_stepsize * a.max_stepsize)) {
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
-#ifdef RELMC_DEBUG_STATUS
-                    status = step2 != step2 ? 20 : 21;
-#else
-                    status = 2;
-#endif
-                    iterating = false;
+                    status = 2; iterating = false;
                 } else {
                     rp = row_min(rp); rd = row_min(rd);
                     alphap = __builtin_fmin(a.xi * rp, 1.0);
@@ -574,31 +611,41 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
                         if (l_on[s]) {
-                            LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);
-                            LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
                             if (l_act[s]) {
-                                lzp[s] = __builtin_fma(alphap, ldzp[s], lzp[s]); lzm[s] = __builtin_fma(alphap, ldzm[s], lzm[s]);
-                                lmup[s] = __builtin_fma(alphad, ldmup[s], lmup[s]); lmum[s] = __builtin_fma(alphad, ldmum[s], lmum[s]);
+                                const double hp = LFv[s] - lr[s], hm = -LFv[s] - lr[s];
+                                const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
+                                const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
+                                const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
+                                lzp[s] = __builtin_fma(alphap, dzp, lzp[s]); lzm[s] = __builtin_fma(alphap, dzm, lzm[s]);
+                                lmup[s] = __builtin_fma(alphad, dmup, lmup[s]); lmum[s] = __builtin_fma(alphad, dmum, lmum[s]);
                                 zl = __builtin_fma(lzp[s], lmup[s], zl); zl = __builtin_fma(lzm[s], lmum[s], zl);
                             }
+                            LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);
+                            LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
                         }
+                        SLOT_FENCE();
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
                         if (i_on[s]) {
                             ilam[s] = __builtin_fma(alphad, dlb[s], ilam[s]);
                             if (i_box[s]) {
+                                const int j = 16 * s + rlane;
+                                const double hp = ip[s] - C.i_hi[j], hm = ilo[s] - ip[s];
+                                const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
+                                const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
+                                const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
                                 ip[s] = __builtin_fma(alphap, dpv[s], ip[s]);
-                                izp[s] = __builtin_fma(alphap, idzp[s], izp[s]); izm[s] = __builtin_fma(alphap, idzm[s], izm[s]);
-                                imup[s] = __builtin_fma(alphad, idmup[s], imup[s]); imum[s] = __builtin_fma(alphad, idmum[s], imum[s]);
+                                izp[s] = __builtin_fma(alphap, dzp, izp[s]); izm[s] = __builtin_fma(alphap, dzm, izm[s]);
+                                imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
                                 zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                             }
                             fl = __builtin_fma(C.i_cost[16 * s + rlane], ip[s], fl);
                         }
+                        SLOT_FENCE();
                     }
-                    BV_0 = __builtin_fma(alphap, SOL_0, BV_0);
-                    BV_1 = __builtin_fma(s1lam ? alphad : alphap, SOL_1, BV_1);
-                    BV_2 = __builtin_fma(alphad, SOL_2, BV_2);
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) { bth[t] = __builtin_fma(alphap, dth[t], bth[t]); bla[t] = __builtin_fma(alphad, dla[t], bla[t]); }
                     zmu = row_sum(zl);
                     fval = row_sum(fl);
                     if (niq > 0) gamma = a.sigma * zmu / (double)niq;
@@ -635,7 +682,7 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
             acc_iters += (uint32_t)it;
             if (WRITE_OUT) {
 #pragma unroll
-                for (int s = 0; s < IS; ++s) S.Ip[16 * s + rlane] = shed[s];
+                for (int s = 0; s < IS; ++s) Ip[16 * s + rlane] = shed[s];
                 if (rlane == 0) {
                     a.dns[sidx] = dns;
                     if (a.status) a.status[sidx] = status;
@@ -643,11 +690,11 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
                 }
                 if (a.nodal) {
 #pragma unroll
-                    for (int t = 0; t < 2; ++t) {
+                    for (int t = 0; t < BS; ++t) {
                         const int i = 16 * t + rlane;
-                        if (i < NBT && ((C.exist_mask >> i) & 1u)) {
+                        if (i < nb) {
                             const int vj = C.b_vinj[i];
-                            a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? S.Ip[vj] : 0.0;
+                            a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? Ip[vj] : 0.0;
                         }
                     }
                 }
@@ -656,7 +703,7 @@ __global__ void __launch_bounds__(64) relmc_eval_kernel(const DevCase* __restric
     }
 
     // ---- per-lane partials; relmc_finalize_kernel reduces them in a fixed order ----------------
-    Partial& P = a.partial[(size_t)blockIdx.x * 64 + lane];
+    Partial& P = a.partial[(size_t)blockIdx.x * (64 * WPB) + tid];
     P.dns = acc_dns; P.dns2 = acc_dns2;
 #pragma unroll
     for (int s = 0; s < IS; ++s) { P.shed[s] = acc_shed[s]; P.cf_inj[s] = acc_cfi[s]; }
@@ -674,51 +721,52 @@ struct DevAcc {
     double sum_nodal[128];
 };
 
-// one workgroup; every output element is summed over (workgroup, row) in a fixed order, so the
-// accumulators are bit-reproducible for a given launch geometry
-__global__ void __launch_bounds__(256) relmc_finalize_kernel(const DevCase* __restrict__ C, const Partial* __restrict__ part,
-                                                             int nblocks, DevAcc* __restrict__ out)
+constexpr int FIN_ITEMS = 8 + 256 + 128;
+
+// One workgroup (one wavefront) per output element; the 16-lane rows are summed lane-strided and
+// combined by a fixed butterfly, so the accumulators are bit-reproducible for a launch geometry.
+__global__ void __launch_bounds__(64) relmc_finalize_kernel(const DevCase* __restrict__ C, const Partial* __restrict__ part,
+                                                            int nrows, DevAcc* __restrict__ out)
 {
-    const int t = threadIdx.x;
-    const int nrows = nblocks * 4;
-    for (int item = t; item < 8 + 256 + 128; item += blockDim.x) {
-        if (item < 6) {
-            long long s = 0;
-            for (int r = 0; r < nrows; ++r) {
-                const Partial& p = part[(size_t)r * 16];
-                const uint32_t v = item == 0 ? p.n : item == 1 ? p.nfail : item == 2 ? p.nsing : item == 3 ? p.ninf : item == 4 ? p.nnc : p.iters;
-                s += v;
+    const int item = blockIdx.x, lane = threadIdx.x;
+    long long si = 0; double sd = 0.0;
+    bool is_int = true; int ln = 0, sl = 0, field = 0;   // field: 0..5 counters, 6 dns, 7 dns2, 8 cf_inj, 9 cf_line, 10 shed
+    bool active = true;
+    if (item < 6) { field = item; }
+    else if (item < 8) { field = item; is_int = false; }
+    else if (item < 8 + 256) {
+        const int k = item - 8;
+        if (k < C->ncomp) { const bool isgen = k < C->ng; const int idx = isgen ? k : k - C->ng; ln = idx & 15; sl = idx >> 4; field = isgen ? 8 : 9; }
+        else active = false;
+    } else {
+        const int i = item - 8 - 256;                  // external bus number
+        const int ii = i < C->nb ? C->b_int[i] : -1;
+        is_int = false;
+        if (ii >= 0 && C->b_vinj[ii] >= 0) { const int j = C->b_vinj[ii]; ln = j & 15; sl = j >> 4; field = 10; }
+        else active = false;
+    }
+    if (active) {
+        for (int r = lane; r < nrows; r += 64) {
+            const Partial& p = part[(size_t)r * 16 + ln];
+            switch (field) {
+                case 0: si += p.n; break; case 1: si += p.nfail; break; case 2: si += p.nsing; break;
+                case 3: si += p.ninf; break; case 4: si += p.nnc; break; case 5: si += p.iters; break;
+                case 6: sd += p.dns; break; case 7: sd += p.dns2; break;
+                case 8: si += p.cf_inj[sl]; break; case 9: si += p.cf_line[sl]; break;
+                default: sd += p.shed[sl]; break;
             }
-            (&out->n)[item] = s;
-        } else if (item < 8) {
-            double s = 0.0;
-            for (int r = 0; r < nrows; ++r) { const Partial& p = part[(size_t)r * 16]; s += item == 6 ? p.dns : p.dns2; }
-            if (item == 6) out->sum_dns = s; else out->sum_dns2 = s;
-        } else if (item < 8 + 256) {
-            const int k = item - 8;
-            long long s = 0;
-            if (k < C->ncomp) {
-                const bool isgen = k < C->ng;
-                const int idx = isgen ? k : k - C->ng;
-                const int ln = idx & 15, sl = idx >> 4;
-                for (int r = 0; r < nrows; ++r) {
-                    const Partial& p = part[(size_t)r * 16 + ln];
-                    s += isgen ? p.cf_inj[sl] : p.cf_line[sl];
-                }
-            }
-            out->comp_fail[k] = s;
-        } else {
-            const int i = item - 8 - 256;
-            double s = 0.0;
-            // i = external bus number; internal tile position through b_int
-            const int ii = i < C->nb ? C->b_int[i] : -1;
-            if (ii >= 0 && C->b_vinj[ii] >= 0) {
-                const int j = C->b_vinj[ii], ln = j & 15, sl = j >> 4;
-                for (int r = 0; r < nrows; ++r) s += part[(size_t)r * 16 + ln].shed[sl];
-            }
-            out->sum_nodal[i] = s;
         }
     }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { si += __shfl_xor(si, off); sd += __shfl_xor(sd, off); }
+    if (lane == 0) {
+        if (item < 6) (&out->n)[item] = si;
+        else if (item == 6) out->sum_dns = sd;
+        else if (item == 7) out->sum_dns2 = sd;
+        else if (item < 8 + 256) out->comp_fail[item - 8] = si;
+        else out->sum_nodal[item - 8 - 256] = sd;
+    }
+    (void)is_int;
 }
 
 // mc_sampling.m:2 materialised: eqstatus[n x ncomp] uint8, one thread per (scenario, 4-component block)
@@ -741,13 +789,12 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCase* __re
     }
 }
 
-// probe used by the unit tests: out[lane] = value broadcast from lane L of the lane's own DPP row,
-// and the row all-reduces (checks the row_newbcast / row_ror semantics the solver relies on)
+// probe used by the unit tests: row broadcast / row all-reduce semantics the solver relies on
 __global__ void relmc_dpp_probe_kernel(const double* __restrict__ in, double* __restrict__ out)
 {
     const int t = threadIdx.x;
     const double v = in[t];
-    out[t] = BCAST(5, v);
+    out[t] = dppd<0x150 + 5>(v);
     out[64 + t] = row_sum(v);
     out[128 + t] = row_max(v);
     out[192 + t] = row_min(v);
