@@ -33,7 +33,7 @@ struct relmc_ctx {
     DevAcc* dacc = nullptr;
     int num_cu = 0;
     int blocks_per_cu = 0;
-    uint32_t scen_doubles = 0, lds_bytes = 0;
+    uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
     double last_kernel_ms = 0.0;
     std::string err;
 };
@@ -92,6 +92,7 @@ int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
     if (rc) return rc;
     a.partial = ctx->dpartial;
     a.scen_doubles = ctx->scen_doubles;
+    a.stash_off = ctx->stash_off;
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -248,18 +249,19 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     for (int i = 0; i < nb; ++i) for (int a : N[i]) blk[a][i] = nb + noff++;
     if (noff > MAXOFF) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: too much fill for the solver workspace");
     C.noff = noff;
-    C.off_rhs = (uint16_t)(4 * (nb + noff));
-    C.off_p = (uint16_t)(C.off_rhs + 4 * nb);
-    C.nws = (uint32_t)C.off_p + 4u * nb;
+    C.off_rhs = (uint16_t)(4 * (nb + noff));          // rhs / solution: 2 doubles per bus
+    C.off_p = 0;                                        // P = inv(D) overwrites D in place
+    C.nws = (uint32_t)C.off_rhs + 2u * nb;
+    if (C.nws >= 0x8000u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver workspace too large");
     auto OFFD = [&](int i) { return 4 * i; };
     auto OFFB = [&](int a, int i) { return 4 * blk[a][i]; };
-    auto OFFY = [&](int i) { return (int)C.off_rhs + 4 * i; };
-    auto OFFP = [&](int i) { return (int)C.off_p + 4 * i; };
+    auto OFFY = [&](int i) { return (int)C.off_rhs + 2 * i; };
+    auto OFFP = [&](int i) { return 4 * i; };
 
     // ---- task list in sequential (right-looking) order, then list scheduling into passes of 16
     struct Task { uint8_t kind; uint16_t o[4]; std::vector<int> rd, wr; };
     std::vector<Task> tasks;
-    auto unit = [](int off) { return off >> 2; };       // dependency unit = one 2x2 block
+    auto unit = [&](int off) { return off < (int)C.off_rhs ? off >> 2 : (int)C.off_rhs / 4 + ((off - (int)C.off_rhs) >> 1); };   // one block / one rhs pair
     for (int i = 0; i < nb; ++i) {
         for (size_t ia = 0; ia < N[i].size(); ++ia)
             for (size_t ib = 0; ib <= ia; ++ib) {
@@ -271,14 +273,14 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
                 tasks.push_back(t);
             }
         for (int a2 : N[i]) {                             // right-hand side as a pseudo-bus: y_a' -= y_i' P W_a'
-            Task t; t.kind = 0; t.o[0] = (uint16_t)OFFY(a2); t.o[1] = (uint16_t)OFFY(i); t.o[2] = (uint16_t)OFFB(a2, i); t.o[3] = (uint16_t)OFFD(i);
+            Task t; t.kind = 0; t.o[0] = (uint16_t)(OFFY(a2) | 0x8000); t.o[1] = (uint16_t)OFFY(i); t.o[2] = (uint16_t)OFFB(a2, i); t.o[3] = (uint16_t)OFFD(i);
             t.rd = {unit(OFFY(i)), unit(OFFB(a2, i)), unit(OFFD(i)), unit(OFFY(a2))}; t.wr = {unit(OFFY(a2))};
             tasks.push_back(t);
         }
     }
     for (int i = 0; i < nb; ++i) {
-        Task t; t.kind = 1; t.o[0] = (uint16_t)OFFD(i); t.o[1] = (uint16_t)OFFY(i); t.o[2] = (uint16_t)OFFP(i); t.o[3] = 0;
-        t.rd = {unit(OFFD(i)), unit(OFFY(i))}; t.wr = {unit(OFFP(i)), unit(OFFY(i))};
+        Task t; t.kind = 1; t.o[0] = (uint16_t)OFFD(i); t.o[1] = (uint16_t)OFFY(i); t.o[2] = 0; t.o[3] = 0;
+        t.rd = {unit(OFFD(i)), unit(OFFY(i))}; t.wr = {unit(OFFD(i)), unit(OFFY(i))};
         tasks.push_back(t);
     }
     for (int a2 = nb - 1; a2 >= 0; --a2)
@@ -289,7 +291,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
             tasks.push_back(t);
         }
     {
-        const int nunits = (int)C.nws / 4 + 1;
+        const int nunits = (int)C.nws / 2 + 2;
         std::vector<int> lastw(nunits, -1), lastr(nunits, -1), pkind, pcount;
         for (const Task& t : tasks) {
             int ready = 0;
@@ -372,7 +374,11 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         C.thr[k] = d->always_up[k] ? 0u : (uint32_t)t;   // mc_sampling.m:40-41
     }
     // ---- launch geometry: dynamic LDS = case tables + schedule + one workspace per scenario row
-    uint32_t scen = C.nws + (uint32_t)EVAL_DOUBLES;
+    const uint32_t eval_doubles = 4u * nl + 3u * ninj;   // Lg, Llx, Lq, LF | Ip, IinvD, INpD: alias the workspace
+    uint32_t scen = C.nws > eval_doubles ? C.nws : eval_doubles;
+    scen = (scen + 1u) & ~1u;
+    ctx->stash_off = scen;
+    scen += 2u * IS * ROWL + NBT;                          // stash: 1/D and Np/D per injection lane; lambda per bus
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     ctx->scen_doubles = scen;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + (uint32_t)C.npass * (uint32_t)sizeof(C.task[0]);

@@ -92,7 +92,8 @@ struct EvalArgs {
     int32_t* status;
     int32_t* iters;
     Partial* partial;               // [gridDim.x * blockDim.x]
-    uint32_t scen_doubles;          // per-scenario LDS doubles (W + evaluation arrays), = 2 mod 4
+    uint32_t scen_doubles;          // per-scenario LDS doubles (workspace + stash), = 2 mod 4
+    uint32_t stash_off;             // start of the per-lane stash behind the workspace
 };
 
 }  // namespace relmc

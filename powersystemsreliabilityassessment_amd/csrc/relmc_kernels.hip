@@ -25,13 +25,12 @@ namespace relmc {
 #define DEVFI __device__ __forceinline__
 
 #ifndef RELMC_WPB
-#define RELMC_WPB 1                 // wavefronts per workgroup (waves never synchronise after the prologue)
+#define RELMC_WPB 4                 // wavefronts per workgroup (they share the case tables; never synchronise after the prologue)
 #endif
 constexpr int WPB = RELMC_WPB;
 #ifndef RELMC_MIN_WAVES
-#define RELMC_MIN_WAVES 1          // min waves per SIMD the register allocator must allow
+#define RELMC_MIN_WAVES 2          // waves per SIMD the register allocator must allow (<= 256 VGPRs)
 #endif
-constexpr int EVAL_DOUBLES = 4 * NLT + 3 * NIT;   // Lg, Llx, Lq, LF | Ip, IinvD, INpD
 
 template <int CTRL>
 DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
@@ -102,14 +101,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     __syncthreads();
     const int nws = (int)C.nws;
     double* const W = reinterpret_cast<double*>(smem + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
-    double* const Lg = W + nws;
-    double* const Llx = Lg + NLT;
-    double* const Lq = Llx + NLT;
-    double* const LF = Lq + NLT;
-    double* const Ip = LF + NLT;
-    double* const IinvD = Ip + NIT;
-    double* const INpD = IinvD + NIT;
-    for (int i = rlane; i < nws; i += ROWL) W[i] = 0.0;      // second rows of the rhs blocks stay 0 forever
+    // The evaluation arrays ALIAS the solver workspace: they are dead once the bus gathers have been
+    // taken into registers, and only then are the KKT blocks written (see "assemble" below).
+    const int nlp = C.nl, nip = C.ninj;
+    double* const Lg = W;
+    double* const Llx = Lg + nlp;
+    double* const Lq = Llx + nlp;
+    double* const LF = Lq + nlp;
+    double* const Ip = LF + nlp;
+    double* const IinvD = Ip + nip;
+    double* const INpD = IinvD + nip;
+    double* const Stash = W + a.stash_off + rlane;          // [2*IS][16]: 1/D and Np/D of this lane's injections
+    double* const Lam = W + a.stash_off + 2 * IS * ROWL;     // [NBT]: bus multipliers lambda_i (kept across the solve)
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
     const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero;
@@ -117,17 +120,27 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     const double eps = 2.220446049250313e-16;
 
     // ---- static per-lane tables -------------------------------------------------------
-    uint32_t linfo[LS]; int lpart[LS]; double lb[LS], lr[LS];
+    uint32_t linfo[LS]; int lpart[LS];
 #pragma unroll
-    for (int s = 0; s < LS; ++s) { const int l = 16 * s + rlane; linfo[s] = C.l_info[l]; lpart[s] = C.l_partner[l]; lb[s] = C.l_b[l]; lr[s] = C.l_rate[l]; }
+    for (int s = 0; s < LS; ++s) { const int l = 16 * s + rlane; linfo[s] = C.l_info[l]; lpart[s] = C.l_partner[l]; }
+#define lb(s) C.l_b[16 * (s) + rlane]
+#define lr(s) C.l_rate[16 * (s) + rlane]
     uint32_t iinfo[IS];
 #pragma unroll
     for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[16 * s + rlane];
 
     // ---- accumulators (nsqMain.m:282-301 in per-sample form) ---------------------------
-    double acc_dns = 0.0, acc_dns2 = 0.0, acc_shed[IS] = {0.0, 0.0, 0.0, 0.0};
-    uint32_t acc_n = 0, acc_nfail = 0, acc_nsing = 0, acc_ninf = 0, acc_nnc = 0, acc_iters = 0;
-    uint32_t acc_cfi[IS] = {0, 0, 0, 0}, acc_cfl[LS] = {0, 0, 0};
+    // They live in this lane's Partial record in HBM (L2-resident, 104 B per lane) and are updated by a
+    // read-modify-write once per scenario: ~25 VGPRs cheaper than carrying them through the solver.
+    Partial& PA = a.partial[(size_t)blockIdx.x * (64 * WPB) + tid];
+    {
+        PA.dns = 0.0; PA.dns2 = 0.0;
+#pragma unroll
+        for (int s = 0; s < IS; ++s) { PA.shed[s] = 0.0; PA.cf_inj[s] = 0; }
+#pragma unroll
+        for (int s = 0; s < LS; ++s) PA.cf_line[s] = 0;
+        PA.n = 0; PA.nfail = 0; PA.nsing = 0; PA.ninf = 0; PA.nnc = 0; PA.iters = 0; PA.pad = 0;
+    }
 
     const int64_t ngroups = (a.n + 3) >> 2;
     const int64_t gwave = (int64_t)blockIdx.x * WPB + (tid >> 6);
@@ -139,18 +152,20 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 
         // per-scenario state ------------------------------------------------------------
         bool l_on[LS], l_act[LS], i_on[IS], i_box[IS];
-        double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS], cB1[LS], cB2[LS];
-        double ip[IS], ilo[IS], ilam[IS], izp[IS], izm[IS], imup[IS], imum[IS];
+        double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS], cBv[LS];
+        double ip[IS], izp[IS], izm[IS], imup[IS], imum[IS];
         double bth[BS], bla[BS], cBd[BS];
         uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, pinned = 0, dropped = 0;
         double gamma = 1.0, fval = 0.0, f0 = 0.0, alphap = 1.0, alphad = 1.0, zmu = 0.0;
         uint32_t niq = 0;
         int it = 0, status = 0;
         bool infeas = false, singular = false, iterating = false;
+        uint32_t lozero = 0;                 // bit s: lower bound of injection slot s relaxed to 0 (island rules 3, 4)
+#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[16 * (s) + rlane])
 #pragma unroll
-        for (int s = 0; s < LS; ++s) { l_on[s] = false; l_act[s] = false; LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cB1[s] = 0; cB2[s] = 0; }
+        for (int s = 0; s < LS; ++s) { l_on[s] = false; l_act[s] = false; LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
 #pragma unroll
-        for (int s = 0; s < IS; ++s) { i_on[s] = false; i_box[s] = false; ip[s] = 0; ilo[s] = 0; ilam[s] = 0; izp[s] = 1; izm[s] = 1; imup[s] = 1; imum[s] = 1; }
+        for (int s = 0; s < IS; ++s) { i_on[s] = false; i_box[s] = false; ip[s] = 0; izp[s] = 1; izm[s] = 1; imup[s] = 1; imum[s] = 1; }
 #pragma unroll
         for (int t = 0; t < BS; ++t) { bth[t] = 0; bla[t] = 0; cBd[t] = 0; }
 
@@ -201,7 +216,6 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 const int j = 16 * s + rlane;
                 const uint32_t kind = (iinfo[s] >> 8) & 0xff;
                 i_on[s] = kind == IK_VIRTUAL || (kind == IK_REAL && !outbit(o0, o1, o2, o3, j));
-                ilo[s] = C.i_lo[j];
             }
 
             // ===== topology: adjacency, isolated buses, islands ===============================
@@ -271,15 +285,15 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             infeas = true;
                         } else if (n_load && !n_gen) {           // rule 3: no generation -> all load shed (p fixed 0)
 #pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL) ilo[s] = 0.0;
+                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL) lozero |= 1u << s;
                         } else if (losum > 1e-9) {               // rule 4: over-generation -> relax Pmin
 #pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_REAL) ilo[s] = 0.0;
+                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_REAL) lozero |= 1u << s;
                             infeas = true;
                         }
                         uint32_t nfree = 0;
 #pragma unroll
-                        for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[16 * s + rlane] - ilo[s] > 0.0) nfree += 1u;
+                        for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[16 * s + rlane] - ILO(s) > 0.0) nfree += 1u;
                         nfree = row_add(nfree);
                         if (!nfree) dropped |= 1u << pin;        // rule 5: dependent balance rows
                         pinned |= 1u << pin;
@@ -294,13 +308,10 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 const uint32_t inf = linfo[s];
                 if ((inf >> 24) & LF_OWNER) {
                     const int f = inf & 0xff, t = (inf >> 8) & 0xff;
-                    double v = l_on[s] ? lb[s] : 0.0;
+                    double v = l_on[s] ? lb(s) : 0.0;
                     const int pr = lpart[s];
                     if (pr >= 0 && !outbit(o0, o1, o2, o3, ng + pr)) v += C.l_b[pr];
-                    v = -v;
-                    const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;    // block (hi, lo): rows of hi, columns of lo
-                    cB1[s] = (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) ? 0.0 : v;   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
-                    cB2[s] = (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) ? 0.0 : v;   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
+                    cBv[s] = -v;                 // -(b_l + b_partner) of the in-service lines of this bus pair
                 }
             }
 #pragma unroll
@@ -323,7 +334,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
                 if (l_act[s]) {
-                    const double h = -lr[s];                       // x0: all angles 0 -> flow 0
+                    const double h = -lr(s);                       // x0: all angles 0 -> flow 0
                     double z = a.z0; if (h < -a.z0) z = -h;
                     double mu = a.z0; if (1.0 / z > a.z0) mu = 1.0 / z;
                     lzp[s] = z; lzm[s] = z; lmup[s] = mu; lmum[s] = mu;
@@ -334,7 +345,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             for (int s = 0; s < IS; ++s) {
                 const int j = 16 * s + rlane;
                 if (i_on[s]) {
-                    const double hi = C.i_hi[j], lo = ilo[s];
+                    const double hi = C.i_hi[j], lo = ILO(s);
                     i_box[s] = hi - lo > eps;
                     ip[s] = i_box[s] ? 0.5 * (lo + hi) : hi;
                     if (i_box[s]) {
@@ -347,6 +358,8 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     fl += C.i_cost[j] * ip[s];
                 }
             }
+#pragma unroll
+            for (int t = 0; t < BS; ++t) if (16 * t + rlane < nb) Lam[16 * t + rlane] = 0.0;
             niq = row_add(nq);
             fval = row_sum(fl);
             f0 = fval;
@@ -367,9 +380,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     const int l = 16 * s + rlane;
                     double g = 0.0, lx = 0.0, q = 0.0;
                     if (l_on[s]) {
-                        lx = LGv[s];
+                        lx = LGv[s];                 // G_l = b_l (lambda_f - lambda_t), carried incrementally
                         if (l_act[s]) {
-                            const double b = lb[s], rr = lr[s];
+                            const double b = lb(s), rr = lr(s);
                             const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
                             const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
                             g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
@@ -381,7 +394,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         }
                     }
                     gown[s] = g;
-                    Lg[l] = g; Llx[l] = lx; Lq[l] = lx + q; LF[l] = LFv[s];
+                    if (l < nlp) { Lg[l] = g; Llx[l] = lx; Lq[l] = lx + q; LF[l] = LFv[s]; }   // arrays are nl / ninj long (they alias W)
                     SLOT_FENCE();
                 }
 #pragma unroll
@@ -393,10 +406,10 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         mx_x = __builtin_fmax(mx_x, __builtin_fabs(pv));
                         nanx = nanx || pv != pv;
                         if (i_box[s]) {
-                            const double hp = pv - C.i_hi[j], hm = ilo[s] - pv;
+                            const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                             const double D = imup[s] * rzp + imum[s] * rzm;
-                            const double lxp = C.i_cost[j] - ilam[s] + (imup[s] - imum[s]);
+                            const double lxp = C.i_cost[j] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                             const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
                             invD = frcp(D); npd = np * invD;
                             mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lxp));
@@ -405,27 +418,28 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(imup[s], imum[s]));
                         }
                     }
-                    Ip[j] = pv; IinvD[j] = invD; INpD[j] = npd;
+                    if (j < nip) { Ip[j] = pv; IinvD[j] = invD; INpD[j] = npd; }
+                    Stash[16 * (2 * s)] = invD; Stash[16 * (2 * s + 1)] = npd;
                     SLOT_FENCE();
                 }
-                // off-diagonal KKT blocks of the line pairs (weighted Laplacian entry + constant B entries)
+                // ---- assemble: gather everything the KKT blocks need into registers ... -------------
+                double vown[LS];
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
+                    vown[s] = 0.0;
                     const uint32_t inf = linfo[s];
                     if ((inf >> 24) & LF_OWNER) {
-                        const int l = 16 * s + rlane, f = inf & 0xff, t = (inf >> 8) & 0xff;
+                        const int f = inf & 0xff, t = (inf >> 8) & 0xff;
                         double gs = gown[s];
                         if (lpart[s] >= 0) gs += Lg[lpart[s]];
-                        const double v = (((pinned >> f) | (pinned >> t)) & 1u) ? 0.0 : -gs;
-                        double* blk = W + C.l_blk[l];
-                        st2(blk, v, cB1[s]); st2(blk + 2, cB2[s], 0.0);
+                        vown[s] = (((pinned >> f) | (pinned >> t)) & 1u) ? 0.0 : -gs;   // pinned columns removed
                     }
                 }
-                for (int z = rlane; z < nzero; z += ROWL) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
-                // bus gathers -> diagonal KKT blocks and right-hand sides
+                double d00[BS], d11[BS], r0[BS], r1[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
                     const int bi = 16 * t + rlane;
+                    d00[t] = 0; d11[t] = 0; r0[t] = 0; r1[t] = 0;
                     if (bi < nb) {
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
                         const int nlb = C.b_nline[bi];
@@ -443,27 +457,45 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             const int j = C.b_inj[bi][e];
                             bal -= Ip[j]; E += IinvD[j]; ssum += INpD[j];
                         }
-                        double d00, d11, r0, r1;
                         if ((pinned >> bi) & 1u) {        // fixed angle: identity row; its multiplier is -lx
-                            d00 = 1.0; r0 = 0.0;
+                            d00[t] = 1.0; r0[t] = 0.0;
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(lx));
                         } else {
-                            d00 = md; r0 = -nq_;
+                            d00[t] = md; r0[t] = -nq_;
                             mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lx));
                         }
                         if ((dropped >> bi) & 1u) {       // dependent balance row
-                            d11 = -1.0; r1 = 0.0;
+                            d11[t] = -1.0; r1[t] = 0.0;
                         } else {
-                            d11 = -E; r1 = -bal - ssum;
+                            d11[t] = -E; r1[t] = -bal - ssum;
                             mx_gh = __builtin_fmax(mx_gh, __builtin_fabs(bal));
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(bla[t]));
                         }
                         mx_x = __builtin_fmax(mx_x, __builtin_fabs(bth[t]));
                         nanx = nanx || bth[t] != bth[t];
-                        st2(W + 4 * bi, d00, cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11);
-                        st2(W + off_rhs + 4 * bi, r0, r1);
                     }
-                    SLOT_FENCE();
+                }
+                // ---- ... then overwrite the workspace (same LDS words as the evaluation arrays) ------
+                RELOAD_FENCE();
+#pragma unroll
+                for (int s = 0; s < LS; ++s) {
+                    if ((linfo[s] >> 24) & LF_OWNER) {
+                        const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                        const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;    // block (hi, lo): rows of hi, columns of lo
+                        const double c1 = (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) ? 0.0 : cBv[s];   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
+                        const double c2 = (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) ? 0.0 : cBv[s];   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
+                        double* blk = W + C.l_blk[16 * s + rlane];
+                        st2(blk, vown[s], c1); st2(blk + 2, c2, 0.0);
+                    }
+                }
+                for (int z = rlane; z < nzero; z += ROWL) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
+#pragma unroll
+                for (int t = 0; t < BS; ++t) {
+                    const int bi = 16 * t + rlane;
+                    if (bi < nb) {
+                        st2(W + 4 * bi, d00[t], cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11[t]);
+                        st2(W + off_rhs + 2 * bi, r0[t], r1[t]);
+                    }
                 }
 
                 // ---- convergence test (mips.m feascond/gradcond/compcond/costcond) --------------
@@ -491,37 +523,42 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 it += 1;
 #ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
-                for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'
+                for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
                     if (rlane < C.pass_ntask[p]) {
                         const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
-                        double* T = W + (dsc.x & 0xffffu);
+                        const bool vec = (dsc.x & 0x8000u) != 0;            // rhs pseudo-bus: Wa = [y_i'; 0], T = y_a'
+                        double* T = W + (dsc.x & 0x7fffu);
                         const double* Wa = W + (dsc.x >> 16);
                         const double* Wb = W + (dsc.y & 0xffffu);
                         const double* D = W + (dsc.y >> 16);
                         const d2 dA = ld2(D), dB = ld2(D + 2);
-                        const d2 a0 = ld2(Wa), a1 = ld2(Wa + 2), b0 = ld2(Wb), b1 = ld2(Wb + 2);
-                        d2 t0 = ld2(T), t1 = ld2(T + 2);
+                        const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
+                        d2 t0 = ld2(T);
                         const double pm = dA.x, pb = dA.y, pe = -dB.y;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
                         const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
-                        const double g10 = __builtin_fma(a1.x, P00, a1.y * P01), g11 = __builtin_fma(a1.x, P01, a1.y * P11);
                         t0.x -= __builtin_fma(g00, b0.x, g01 * b0.y); t0.y -= __builtin_fma(g00, b1.x, g01 * b1.y);
-                        t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
-                        st2(T, t0.x, t0.y); st2(T + 2, t1.x, t1.y);
+                        st2(T, t0.x, t0.y);
+                        if (!vec) {
+                            const d2 a1 = ld2(Wa + 2);
+                            d2 t1 = ld2(T + 2);
+                            const double g10 = __builtin_fma(a1.x, P00, a1.y * P01), g11 = __builtin_fma(a1.x, P01, a1.y * P11);
+                            t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
+                            st2(T + 2, t1.x, t1.y);
+                        }
                     }
                 }
-                for (int p = npu; p < npu + npi; ++p) {      // P = inv(D); y <- P*y
+                for (int p = npu; p < npu + npi; ++p) {      // D <- P = inv(D) in place; y <- P*y
                     if (rlane < C.pass_ntask[p]) {
                         const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
-                        const double* D = W + (dsc.x & 0xffffu);
+                        double* D = W + (dsc.x & 0xffffu);
                         double* Y = W + (dsc.x >> 16);
-                        double* P = W + (dsc.y & 0xffffu);
                         const d2 dA = ld2(D), dB = ld2(D + 2), y = ld2(Y);
                         const double pm = dA.x, pb = dA.y, pe = -dB.y;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
-                        st2(P, P00, P01); st2(P + 2, P01, P11);
+                        st2(D, P00, P01); st2(D + 2, P01, P11);
                         st2(Y, __builtin_fma(P00, y.x, P01 * y.y), __builtin_fma(P01, y.x, P11 * y.y));
                     }
                 }
@@ -542,14 +579,14 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 #endif
                 RELOAD_FENCE();
                 // ---- step lengths ---------------------------------------------------------------------
-                const double* X = W + off_rhs;               // solution: block i = [dtheta_i, dlambda_i, 0, 0]
+                const double* X = W + off_rhs;               // solution: X[2i] = dtheta_i, X[2i+1] = dlambda_i
                 double step2 = 0.0;
                 double dth[BS], dla[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
                     const int bi = 16 * t + rlane;
                     dth[t] = 0; dla[t] = 0;
-                    if (bi < nb) { const d2 x = ld2(X + 4 * bi); dth[t] = x.x; dla[t] = x.y; step2 = __builtin_fma(x.x, x.x, __builtin_fma(x.y, x.y, step2)); }
+                    if (bi < nb) { const d2 x = ld2(X + 2 * bi); dth[t] = x.x; dla[t] = x.y; step2 = __builtin_fma(x.x, x.x, __builtin_fma(x.y, x.y, step2)); }
                 }
                 // Two passes over the slack/multiplier steps: pass 1 only finds the step lengths (ratio
                 // tests), pass 2 recomputes dz, dmu and applies them.  Recomputing ~150 VALU instructions
@@ -561,11 +598,11 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     dF[s] = 0; dG[s] = 0;
                     if (l_on[s]) {
                         const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
-                        const d2 xf = ld2(X + 4 * f), xt = ld2(X + 4 * t);
-                        dF[s] = lb[s] * (xf.x - xt.x);
-                        dG[s] = lb[s] * (xf.y - xt.y);
+                        const d2 xf = ld2(X + 2 * f), xt = ld2(X + 2 * t);
+                        dF[s] = lb(s) * (xf.x - xt.x);
+                        dG[s] = lb(s) * (xf.y - xt.y);
                         if (l_act[s]) {
-                            const double hp = LFv[s] - lr[s], hm = -LFv[s] - lr[s];
+                            const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
                             const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
                             const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
@@ -583,10 +620,10 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     const int j = 16 * s + rlane;
                     dpv[s] = 0; dlb[s] = 0;
                     if (i_on[s]) {
-                        dlb[s] = X[4 * (iinfo[s] & 0xff) + 1];
+                        dlb[s] = X[2 * (iinfo[s] & 0xff) + 1];
                         if (i_box[s]) {
-                            dpv[s] = __builtin_fma(dlb[s], IinvD[j], -INpD[j]);   // dp = (-Np + dlam)/D
-                            const double hp = ip[s] - C.i_hi[j], hm = ilo[s] - ip[s];
+                            dpv[s] = __builtin_fma(dlb[s], Stash[16 * (2 * s)], -Stash[16 * (2 * s + 1)]);   // dp = (-Np + dlam)/D
+                            const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
                             const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
@@ -612,7 +649,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     for (int s = 0; s < LS; ++s) {
                         if (l_on[s]) {
                             if (l_act[s]) {
-                                const double hp = LFv[s] - lr[s], hm = -LFv[s] - lr[s];
+                                const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                                 const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
                                 const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
                                 const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
@@ -628,10 +665,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
                         if (i_on[s]) {
-                            ilam[s] = __builtin_fma(alphad, dlb[s], ilam[s]);
                             if (i_box[s]) {
                                 const int j = 16 * s + rlane;
-                                const double hp = ip[s] - C.i_hi[j], hm = ilo[s] - ip[s];
+                                const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                                 const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                                 const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
                                 const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
@@ -645,7 +681,10 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         SLOT_FENCE();
                     }
 #pragma unroll
-                    for (int t = 0; t < BS; ++t) { bth[t] = __builtin_fma(alphap, dth[t], bth[t]); bla[t] = __builtin_fma(alphad, dla[t], bla[t]); }
+                    for (int t = 0; t < BS; ++t) {
+                        bth[t] = __builtin_fma(alphap, dth[t], bth[t]); bla[t] = __builtin_fma(alphad, dla[t], bla[t]);
+                        if (16 * t + rlane < nb) Lam[16 * t + rlane] = bla[t];
+                    }
                     zmu = row_sum(zl);
                     fval = row_sum(fl);
                     if (niq > 0) gamma = a.sigma * zmu / (double)niq;
@@ -667,22 +706,24 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     const double v = ip[s] * base - C.i_pmin_mw[j];     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
-                acc_shed[s] += shed[s];
-                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(o0, o1, o2, o3, j)) acc_cfi[s] += 1;
+                if (shed[s] != 0.0) PA.shed[s] += shed[s];
+                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(o0, o1, o2, o3, j)) PA.cf_inj[s] += 1;
             }
 #pragma unroll
             for (int s = 0; s < LS; ++s)
-                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(o0, o1, o2, o3, ng + 16 * s + rlane)) acc_cfl[s] += 1;
-            acc_n += 1;
-            acc_dns += dns; acc_dns2 = __builtin_fma(dns, dns, acc_dns2);
-            acc_nfail += fail ? 1 : 0;
-            acc_nsing += status == 3 ? 1 : 0;
-            acc_nnc += (status == 1 || status == 2) ? 1 : 0;
-            acc_ninf += infeas ? 1 : 0;
-            acc_iters += (uint32_t)it;
+                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(o0, o1, o2, o3, ng + 16 * s + rlane)) PA.cf_line[s] += 1;
+            if (rlane == 0) {                       // row-uniform quantities: one lane per scenario row
+                PA.n += 1;
+                if (dns != 0.0) { PA.dns += dns; PA.dns2 = __builtin_fma(dns, dns, PA.dns2); }
+                if (fail) PA.nfail += 1;
+                if (status == 3) PA.nsing += 1;
+                if (status == 1 || status == 2) PA.nnc += 1;
+                if (infeas) PA.ninf += 1;
+                PA.iters += (uint32_t)it;
+            }
             if (WRITE_OUT) {
 #pragma unroll
-                for (int s = 0; s < IS; ++s) Ip[16 * s + rlane] = shed[s];
+                for (int s = 0; s < IS; ++s) if (16 * s + rlane < nip) Ip[16 * s + rlane] = shed[s];
                 if (rlane == 0) {
                     a.dns[sidx] = dns;
                     if (a.status) a.status[sidx] = status;
@@ -702,15 +743,6 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         }
     }
 
-    // ---- per-lane partials; relmc_finalize_kernel reduces them in a fixed order ----------------
-    Partial& P = a.partial[(size_t)blockIdx.x * (64 * WPB) + tid];
-    P.dns = acc_dns; P.dns2 = acc_dns2;
-#pragma unroll
-    for (int s = 0; s < IS; ++s) { P.shed[s] = acc_shed[s]; P.cf_inj[s] = acc_cfi[s]; }
-#pragma unroll
-    for (int s = 0; s < LS; ++s) P.cf_line[s] = acc_cfl[s];
-    P.n = acc_n; P.nfail = acc_nfail; P.nsing = acc_nsing; P.ninf = acc_ninf; P.nnc = acc_nnc; P.iters = acc_iters;
-    P.pad = 0;
 }
 
 // device image of relmc_acc (include/relmc.h): 6 + 256 int64, then 2 + 128 doubles
