@@ -34,6 +34,7 @@ struct relmc_ctx {
     int num_cu = 0;
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
+    unsigned long long* dtiming = nullptr; int timing_waves = 0;
     double last_kernel_ms = 0.0;
     std::string err;
 };
@@ -93,6 +94,12 @@ int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
     a.partial = ctx->dpartial;
     a.scen_doubles = ctx->scen_doubles;
     a.stash_off = ctx->stash_off;
+#ifdef RELMC_PHASE_TIMING
+    if (!ctx->dtiming) HIP_TRY(ctx, hipMalloc(&ctx->dtiming, sizeof(unsigned long long) * 8 * 65536));
+    a.timing = ctx->dtiming; ctx->timing_waves = blocks * WPB;
+#else
+    a.timing = nullptr;
+#endif
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
     hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
     HIP_TRY(ctx, hipGetLastError());
@@ -293,6 +300,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     {
         const int nunits = (int)C.nws / 2 + 2;
         std::vector<int> lastw(nunits, -1), lastr(nunits, -1), pkind, pcount;
+        for (int q = 0; q < MAXPASS; ++q) for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[q][r][k] = 0xffff;   // null task
         for (const Task& t : tasks) {
             int ready = 0;
             for (int r : t.rd) if (lastw[r] + 1 > ready) ready = lastw[r] + 1;          // RAW
@@ -301,7 +309,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
             int p = -1;
             for (int q = ready; q < (int)pkind.size(); ++q) if (pkind[q] == t.kind && pcount[q] < ROWL) { p = q; break; }
             if (p < 0) { pkind.push_back(t.kind); pcount.push_back(0); p = (int)pkind.size() - 1; }
-            if (p >= MAXPASS) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver schedule exceeds MAXPASS");
+            if (p >= MAXPASS - 1) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver schedule exceeds MAXPASS");
             for (int k = 0; k < 4; ++k) C.task[p][pcount[p]][k] = t.o[k];
             pcount[p]++;
             for (int r : t.rd) if (p > lastr[r]) lastr[r] = p;
@@ -347,6 +355,13 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
             C.b_line[bus][C.b_nline[bus]++] = (uint8_t)(l | (side ? 0x80 : 0));
         }
     }
+    int maxdeg = 0, maxinj_ = 0;
+    for (int i = 0; i < nb; ++i) {
+        uint64_t pk = 0;
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_nline[i] ? C.b_line[i][e] : 0x7f) << (8 * e);
+        C.b_line8[i] = pk;
+        if (C.b_nline[i] > maxdeg) maxdeg = C.b_nline[i];
+    }
     int nzero = 0;
     for (int k = nb; k < nb + noff; ++k) if (!has_line[k]) C.zero_off[nzero++] = (uint16_t)(4 * k);
     C.nzero = (uint16_t)nzero;
@@ -366,6 +381,13 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
             C.b_vinj[bus] = (int8_t)j;
         }
     }
+    for (int i = 0; i < nb; ++i) {
+        uint64_t pk = 0;
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : 0x7f) << (8 * e);
+        C.b_inj8[i] = pk;
+        if (C.b_ninj[i] > maxinj_) maxinj_ = C.b_ninj[i];
+    }
+    C.maxdeg = (uint16_t)maxdeg; C.maxinj = (uint16_t)maxinj_;
     // Bernoulli thresholds: fail iff draw_u32 < floor(U * 2^32)   (mc_sampling.m:35, strict '<')
     for (int k = 0; k < ncomp; ++k) {
         double t = std::floor(d->unavail[k] * 4294967296.0);
@@ -374,14 +396,14 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         C.thr[k] = d->always_up[k] ? 0u : (uint32_t)t;   // mc_sampling.m:40-41
     }
     // ---- launch geometry: dynamic LDS = case tables + schedule + one workspace per scenario row
-    const uint32_t eval_doubles = 4u * nl + 3u * ninj;   // Lg, Llx, Lq, LF | Ip, IinvD, INpD: alias the workspace
+    const uint32_t eval_doubles = 4u * (nl + 1) + 4u * (ninj + 1);   // line / injection records (+1 zero record each): alias the workspace
     uint32_t scen = C.nws > eval_doubles ? C.nws : eval_doubles;
     scen = (scen + 1u) & ~1u;
     ctx->stash_off = scen;
     scen += 2u * IS * ROWL + NBT;                          // stash: 1/D and Np/D per injection lane; lambda per bus
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     ctx->scen_doubles = scen;
-    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + (uint32_t)C.npass * (uint32_t)sizeof(C.task[0]);
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
     ctx->lds_bytes = ((case_bytes + 15u) & ~15u) + 4u * WPB * scen * (uint32_t)sizeof(double);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
@@ -600,18 +622,42 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     return RELMC_OK;
 }
 
-// test hook: DPP semantics probe (tests/test_gpu_parity.py); in[64] -> out[384]
+// introspection: {npass_upd, npass_inv, npass_bwd, noff, nzero, nws, lds_bytes, blocks_per_cu, total tasks}
+int32_t relmc_debug_schedule(const relmc_ctx* ctx, int32_t* out9)
+{
+    if (!ctx || !out9 || !ctx->has_case) return RELMC_ERR_INVALID;
+    const DevCase& C = ctx->hcase;
+    int ntask = 0;
+    for (int p = 0; p < C.npass; ++p) ntask += C.pass_ntask[p];
+    out9[0] = C.npass_upd; out9[1] = C.npass_inv; out9[2] = C.npass - C.npass_upd - C.npass_inv; out9[3] = C.noff;
+    out9[4] = C.nzero; out9[5] = (int)C.nws; out9[6] = (int)ctx->lds_bytes; out9[7] = ctx->blocks_per_cu; out9[8] = ntask;
+    return RELMC_OK;
+}
+
+// profiling hook (only meaningful in -DRELMC_PHASE_TIMING builds): per-phase cycle sums of the last launch
+int32_t relmc_debug_phase_cycles(relmc_ctx* ctx, unsigned long long* out8)
+{
+    if (!ctx || !out8) return RELMC_ERR_INVALID;
+    for (int k = 0; k < 8; ++k) out8[k] = 0;
+    if (!ctx->dtiming || ctx->timing_waves <= 0) return RELMC_OK;
+    std::vector<unsigned long long> h((size_t)ctx->timing_waves * 8);
+    HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dtiming, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
+    for (int w = 0; w < ctx->timing_waves; ++w) for (int k = 0; k < 8; ++k) out8[k] += h[(size_t)w * 8 + k];
+    return RELMC_OK;
+}
+
+// test hook: DPP semantics probe (tests/test_gpu_parity.py); in[64] -> out[512]
 int32_t relmc_dpp_probe(relmc_ctx* ctx, const double* in_host, double* out_host)
 {
     if (!ctx || !in_host || !out_host) return RELMC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     double* din = nullptr; double* dout = nullptr;
     HIP_TRY(ctx, hipMalloc(&din, sizeof(double) * 64));
-    HIP_TRY(ctx, hipMalloc(&dout, sizeof(double) * 384));
+    HIP_TRY(ctx, hipMalloc(&dout, sizeof(double) * 512));
     HIP_TRY(ctx, hipMemcpy(din, in_host, sizeof(double) * 64, hipMemcpyHostToDevice));
     hipLaunchKernelGGL(relmc_dpp_probe_kernel, dim3(1), dim3(64), 0, ctx->stream, din, dout);
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
-    HIP_TRY(ctx, hipMemcpy(out_host, dout, sizeof(double) * 384, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out_host, dout, sizeof(double) * 512, hipMemcpyDeviceToHost));
     (void)hipFree(din); (void)hipFree(dout);
     return RELMC_OK;
 }

@@ -42,6 +42,9 @@ struct DevCase {
     uint32_t nws;                   // doubles in W
     uint16_t off_rhs, off_p;
     uint16_t npass, npass_upd, npass_inv, nzero;
+    uint16_t maxdeg, maxinj, pad1, pad2;   // largest number of lines / injections at one bus
+    uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), 0x7f = none
+    uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0x7f = none
     // lines
     double l_b[NLT];
     double l_rate[NLT];             // p.u. (0 = unlimited)
@@ -94,6 +97,7 @@ struct EvalArgs {
     Partial* partial;               // [gridDim.x * blockDim.x]
     uint32_t scen_doubles;          // per-scenario LDS doubles (workspace + stash), = 2 mod 4
     uint32_t stash_off;             // start of the per-lane stash behind the workspace
+    unsigned long long* timing;     // profiling builds: [waves][8] phase cycle counters (else null)
 };
 
 }  // namespace relmc

@@ -55,6 +55,14 @@ DEVFI double frcp(double x)
     return r;
 }
 
+// 1/x to ~2e-15 relative (measured on gfx950: raw v_rcp_f64 4.4e-8, one Newton step 2.0e-15, two steps exact):
+// used where only a ratio-test bound is needed
+DEVFI double frcp1(double x)
+{
+    const double r = __builtin_amdgcn_rcp(x);
+    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+
 // Philox4x32-10 (Salmon et al. SC'11); counter (i_lo, i_hi, block, 0), key = seed
 DEVFI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
 {
@@ -85,6 +93,16 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define RELOAD_FENCE() __asm__ volatile("" ::: "memory")
 // keeps the unrolled per-slot bodies from being interleaved (each body has ~20 live temporaries)
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// optional per-phase cycle accounting (profiling builds only: -DRELMC_PHASE_TIMING)
+#ifdef RELMC_PHASE_TIMING
+#define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt0_ = __builtin_readcyclecounter();
+#define PT_MARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_[k] += n_ - pt0_; pt0_ = n_; }
+#define PT_FLUSH if (a.timing && lane == 0) { for (int k = 0; k < 8; ++k) a.timing[((size_t)blockIdx.x * WPB + (tid >> 6)) * 8 + k] = pt_[k]; }
+#else
+#define PT_DECL
+#define PT_MARK(k)
+#define PT_FLUSH
+#endif
 
 template <bool FROM_RNG, bool WRITE_OUT>
 __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCase* __restrict__ gcase, const EvalArgs a)
@@ -92,7 +110,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevCase& C = *reinterpret_cast<DevCase*>(smem);
     const int tid = threadIdx.x, lane = tid & 63, rlane = lane & 15, row = tid >> 4;
-    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + (uint32_t)gcase->npass * (uint32_t)sizeof(C.task[0]);
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)gcase->npass + 1u) * (uint32_t)sizeof(C.task[0]);   // +1: descriptor prefetch
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(gcase);
         uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
@@ -103,14 +121,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     double* const W = reinterpret_cast<double*>(smem + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
     // The evaluation arrays ALIAS the solver workspace: they are dead once the bus gathers have been
     // taken into registers, and only then are the KKT blocks written (see "assemble" below).
+    // line record l = {g, lx, q, F} at LR + 4l, injection record j = {p, 1/D, Np/D, -} at IR + 4j; record nl / ninj
+    // is an all-zero dummy that unused gather slots point to.
     const int nlp = C.nl, nip = C.ninj;
-    double* const Lg = W;
-    double* const Llx = Lg + nlp;
-    double* const Lq = Llx + nlp;
-    double* const LF = Lq + nlp;
-    double* const Ip = LF + nlp;
-    double* const IinvD = Ip + nip;
-    double* const INpD = IinvD + nip;
+    double* const LR = W;
+    double* const IR = W + 4 * (nlp + 1);
+    const int maxdeg = C.maxdeg, maxinj = C.maxinj;
     double* const Stash = W + a.stash_off + rlane;          // [2*IS][16]: 1/D and Np/D of this lane's injections
     double* const Lam = W + a.stash_off + 2 * IS * ROWL;     // [NBT]: bus multipliers lambda_i (kept across the solve)
 
@@ -142,6 +158,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         PA.n = 0; PA.nfail = 0; PA.nsing = 0; PA.ninf = 0; PA.nnc = 0; PA.iters = 0; PA.pad = 0;
     }
 
+    PT_DECL
     const int64_t ngroups = (a.n + 3) >> 2;
     const int64_t gwave = (int64_t)blockIdx.x * WPB + (tid >> 6);
     const int64_t gstride = (int64_t)gridDim.x * WPB;
@@ -151,7 +168,13 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         RELOAD_FENCE();
 
         // per-scenario state ------------------------------------------------------------
-        bool l_on[LS], l_act[LS], i_on[IS], i_box[IS];
+        // per-lane status bits (one VGPR instead of 14 lane masks in SGPRs): line in service / has a flow limit,
+        // injection in service / boxed (has inequality rows)
+        uint32_t sf = 0;
+#define L_ON(s) (((sf >> (s)) & 1u) != 0)
+#define L_ACT(s) (((sf >> (3 + (s))) & 1u) != 0)
+#define I_ON(s) (((sf >> (6 + (s))) & 1u) != 0)
+#define I_BOX(s) (((sf >> (10 + (s))) & 1u) != 0)
         double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS], cBv[LS];
         double ip[IS], izp[IS], izm[IS], imup[IS], imum[IS];
         double bth[BS], bla[BS], cBd[BS];
@@ -163,9 +186,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         uint32_t lozero = 0;                 // bit s: lower bound of injection slot s relaxed to 0 (island rules 3, 4)
 #define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[16 * (s) + rlane])
 #pragma unroll
-        for (int s = 0; s < LS; ++s) { l_on[s] = false; l_act[s] = false; LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
+        for (int s = 0; s < LS; ++s) { LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
 #pragma unroll
-        for (int s = 0; s < IS; ++s) { i_on[s] = false; i_box[s] = false; ip[s] = 0; izp[s] = 1; izm[s] = 1; imup[s] = 1; imum[s] = 1; }
+        for (int s = 0; s < IS; ++s) { ip[s] = 0; izp[s] = 1; izm[s] = 1; imup[s] = 1; imum[s] = 1; }
 #pragma unroll
         for (int t = 0; t < BS; ++t) { bth[t] = 0; bla[t] = 0; cBd[t] = 0; }
 
@@ -208,14 +231,15 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             for (int s = 0; s < LS; ++s) {
                 const int l = 16 * s + rlane;
                 const uint32_t fl = linfo[s] >> 24;
-                l_on[s] = (fl & LF_EXISTS) && !outbit(o0, o1, o2, o3, ng + l);
-                l_act[s] = l_on[s] && (fl & LF_LIMITED);
+                const bool on = (fl & LF_EXISTS) && !outbit(o0, o1, o2, o3, ng + l);
+                if (on) sf |= 1u << s;
+                if (on && (fl & LF_LIMITED)) sf |= 1u << (3 + s);
             }
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
                 const int j = 16 * s + rlane;
                 const uint32_t kind = (iinfo[s] >> 8) & 0xff;
-                i_on[s] = kind == IK_VIRTUAL || (kind == IK_REAL && !outbit(o0, o1, o2, o3, j));
+                if (kind == IK_VIRTUAL || (kind == IK_REAL && !outbit(o0, o1, o2, o3, j))) sf |= 1u << (6 + s);
             }
 
             // ===== topology: adjacency, isolated buses, islands ===============================
@@ -270,7 +294,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         for (int s = 0; s < IS; ++s) {
                             const int j = 16 * s + rlane;
                             const uint32_t kind = (iinfo[s] >> 8) & 0xff;
-                            inI[s] = i_on[s] && ((R >> (iinfo[s] & 0xff)) & 1u);
+                            inI[s] = I_ON(s) && ((R >> (iinfo[s] & 0xff)) & 1u);
                             if (inI[s]) {
                                 cnt += 1u;
                                 if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
@@ -281,7 +305,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         const uint32_t n_inj = cnt & 0xff, n_load = (cnt >> 8) & 0xff, n_gen = cnt >> 16;
                         if (n_inj && !n_load) {                  // rule 2: no load -> decommit the island's units
 #pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s]) { i_on[s] = false; inI[s] = false; }
+                            for (int s = 0; s < IS; ++s) if (inI[s]) { sf &= ~(1u << (6 + s)); inI[s] = false; }
                             infeas = true;
                         } else if (n_load && !n_gen) {           // rule 3: no generation -> all load shed (p fixed 0)
 #pragma unroll
@@ -308,7 +332,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 const uint32_t inf = linfo[s];
                 if ((inf >> 24) & LF_OWNER) {
                     const int f = inf & 0xff, t = (inf >> 8) & 0xff;
-                    double v = l_on[s] ? lb(s) : 0.0;
+                    double v = L_ON(s) ? lb(s) : 0.0;
                     const int pr = lpart[s];
                     if (pr >= 0 && !outbit(o0, o1, o2, o3, ng + pr)) v += C.l_b[pr];
                     cBv[s] = -v;                 // -(b_l + b_partner) of the in-service lines of this bus pair
@@ -333,7 +357,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             uint32_t nq = 0;
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
-                if (l_act[s]) {
+                if (L_ACT(s)) {
                     const double h = -lr(s);                       // x0: all angles 0 -> flow 0
                     double z = a.z0; if (h < -a.z0) z = -h;
                     double mu = a.z0; if (1.0 / z > a.z0) mu = 1.0 / z;
@@ -344,11 +368,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
                 const int j = 16 * s + rlane;
-                if (i_on[s]) {
+                if (I_ON(s)) {
                     const double hi = C.i_hi[j], lo = ILO(s);
-                    i_box[s] = hi - lo > eps;
-                    ip[s] = i_box[s] ? 0.5 * (lo + hi) : hi;
-                    if (i_box[s]) {
+                    const bool box = hi - lo > eps;
+                    if (box) sf |= 1u << (10 + s);
+                    ip[s] = box ? 0.5 * (lo + hi) : hi;
+                    if (box) {
                         const double h = -0.5 * (hi - lo);
                         double z = a.z0; if (h < -a.z0) z = -h;
                         double mu = a.z0; if (1.0 / z > a.z0) mu = 1.0 / z;
@@ -367,6 +392,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             status = singular ? 3 : 0;
         }
 
+        PT_MARK(0)
         // ===== mips main loop =======================================
         while (__any(iterating)) {
             RELOAD_FENCE();
@@ -379,9 +405,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 for (int s = 0; s < LS; ++s) {
                     const int l = 16 * s + rlane;
                     double g = 0.0, lx = 0.0, q = 0.0;
-                    if (l_on[s]) {
+                    if (L_ON(s)) {
                         lx = LGv[s];                 // G_l = b_l (lambda_f - lambda_t), carried incrementally
-                        if (l_act[s]) {
+                        if (L_ACT(s)) {
                             const double b = lb(s), rr = lr(s);
                             const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
                             const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
@@ -394,18 +420,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         }
                     }
                     gown[s] = g;
-                    if (l < nlp) { Lg[l] = g; Llx[l] = lx; Lq[l] = lx + q; LF[l] = LFv[s]; }   // arrays are nl / ninj long (they alias W)
+                    if (l < nlp) { st2(LR + 4 * l, g, lx); st2(LR + 4 * l + 2, lx + q, LFv[s]); }   // nl / ninj records (they alias W)
                     SLOT_FENCE();
                 }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = 16 * s + rlane;
                     double invD = 0.0, npd = 0.0, pv = 0.0;
-                    if (i_on[s]) {
+                    if (I_ON(s)) {
                         pv = ip[s];
                         mx_x = __builtin_fmax(mx_x, __builtin_fabs(pv));
                         nanx = nanx || pv != pv;
-                        if (i_box[s]) {
+                        if (I_BOX(s)) {
                             const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                             const double D = imup[s] * rzp + imum[s] * rzm;
@@ -418,10 +444,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(imup[s], imum[s]));
                         }
                     }
-                    if (j < nip) { Ip[j] = pv; IinvD[j] = invD; INpD[j] = npd; }
+                    if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
                     Stash[16 * (2 * s)] = invD; Stash[16 * (2 * s + 1)] = npd;
                     SLOT_FENCE();
                 }
+                PT_MARK(1)
+                if (rlane == 0) { st2(LR + 4 * nlp, 0.0, 0.0); st2(LR + 4 * nlp + 2, 0.0, 0.0); st2(IR + 4 * nip, 0.0, 0.0); IR[4 * nip + 2] = 0.0; }
                 // ---- assemble: gather everything the KKT blocks need into registers ... -------------
                 double vown[LS];
 #pragma unroll
@@ -431,7 +459,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     if ((inf >> 24) & LF_OWNER) {
                         const int f = inf & 0xff, t = (inf >> 8) & 0xff;
                         double gs = gown[s];
-                        if (lpart[s] >= 0) gs += Lg[lpart[s]];
+                        if (lpart[s] >= 0) gs += LR[4 * lpart[s]];
                         vown[s] = (((pinned >> f) | (pinned >> t)) & 1u) ? 0.0 : -gs;   // pinned columns removed
                     }
                 }
@@ -442,20 +470,28 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     d00[t] = 0; d11[t] = 0; r0[t] = 0; r1[t] = 0;
                     if (bi < nb) {
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
-                        const int nlb = C.b_nline[bi];
-                        for (int e = 0; e < nlb; ++e) {
-                            const uint32_t ent = C.b_line[bi][e];
-                            const int l = ent & 0x7f;
+                        // incidence lists come packed (one 8-byte LDS read each); unused slots point at the zero
+                        // records, so all record loads of a bus are independent and issue back to back
+                        const unsigned long long pl = C.b_line8[bi], pj = C.b_inj8[bi];
+#pragma unroll
+                        for (int e = 0; e < DEGMAX; ++e) {
+                            if (e >= maxdeg) break;
+                            const uint32_t ent = (uint32_t)(pl >> (8 * e)) & 0xffu;
+                            const int l = (ent & 0x7f) == 0x7f ? nlp : (int)(ent & 0x7f);
                             const double sg = (ent & 0x80) ? -1.0 : 1.0;
-                            md += Lg[l];
-                            lx = __builtin_fma(sg, Llx[l], lx);
-                            nq_ = __builtin_fma(sg, Lq[l], nq_);
-                            bal = __builtin_fma(sg, LF[l], bal);
+                            const d2 ra = ld2(LR + 4 * l), rb = ld2(LR + 4 * l + 2);
+                            md += ra.x;
+                            lx = __builtin_fma(sg, ra.y, lx);
+                            nq_ = __builtin_fma(sg, rb.x, nq_);
+                            bal = __builtin_fma(sg, rb.y, bal);
                         }
-                        const int nib = C.b_ninj[bi];
-                        for (int e = 0; e < nib; ++e) {
-                            const int j = C.b_inj[bi][e];
-                            bal -= Ip[j]; E += IinvD[j]; ssum += INpD[j];
+#pragma unroll
+                        for (int e = 0; e < BINJMAX; ++e) {
+                            if (e >= maxinj) break;
+                            const uint32_t ent = (uint32_t)(pj >> (8 * e)) & 0xffu;
+                            const int j = ent == 0x7f ? nip : (int)ent;
+                            const d2 ra = ld2(IR + 4 * j);
+                            bal -= ra.x; E += ra.y; ssum += IR[4 * j + 2];
                         }
                         if ((pinned >> bi) & 1u) {        // fixed angle: identity row; its multiplier is -lx
                             d00[t] = 1.0; r0[t] = 0.0;
@@ -498,16 +534,15 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     }
                 }
 
+                PT_MARK(2)
                 // ---- convergence test (mips.m feascond/gradcond/compcond/costcond) --------------
                 mx_gh = row_max(mx_gh); mx_x = row_max(mx_x); mx_z = row_max(mx_z);
                 mx_lx = row_max(mx_lx); mx_lammu = row_max(mx_lammu);
                 const uint64_t nanb = __ballot(nanx);
                 const bool xnan = ((nanb >> (lane & 48)) & 0xffffull) != 0;
-                const double feascond = mx_gh / (1.0 + __builtin_fmax(mx_x, mx_z));
-                const double gradcond = mx_lx / (1.0 + mx_lammu);
-                const double compcond = zmu / (1.0 + mx_x);
-                const double costcond = __builtin_fabs(fval - f0) / (1.0 + __builtin_fabs(f0));
-                const bool conv = it > 0 && feascond < a.feastol && gradcond < a.gradtol && compcond < a.comptol && costcond < a.costtol;
+                // feascond < feastol etc. with the (positive) denominators multiplied out
+                const bool conv = it > 0 && mx_gh < a.feastol * (1.0 + __builtin_fmax(mx_x, mx_z)) && mx_lx < a.gradtol * (1.0 + mx_lammu) &&
+                                  zmu < a.comptol * (1.0 + mx_x) && __builtin_fabs(fval - f0) < a.costtol * (1.0 + __builtin_fabs(f0));
 #ifdef RELMC_ABLATE_FIXIT
                 if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }
                 else if (false) {}
@@ -517,15 +552,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 else if (it > 0 && (xnan || alphap < a.alpha_min || alphad < a.alpha_min || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
             }
+            PT_MARK(3)
             RELOAD_FENCE();
             if (iterating) {
                 f0 = fval;
                 it += 1;
 #ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
+                // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
+                uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[0][rlane][0]);
                 for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
-                    if (rlane < C.pass_ntask[p]) {
-                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    if ((dsc.x & 0xffffu) != 0xffffu) {
                         const bool vec = (dsc.x & 0x8000u) != 0;            // rhs pseudo-bus: Wa = [y_i'; 0], T = y_a'
                         double* T = W + (dsc.x & 0x7fffu);
                         const double* Wa = W + (dsc.x >> 16);
@@ -548,10 +586,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             st2(T + 2, t1.x, t1.y);
                         }
                     }
+                    dsc = nxt;
                 }
+                PT_MARK(4)
                 for (int p = npu; p < npu + npi; ++p) {      // D <- P = inv(D) in place; y <- P*y
-                    if (rlane < C.pass_ntask[p]) {
-                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    if ((dsc.x & 0xffffu) != 0xffffu) {
                         double* D = W + (dsc.x & 0xffffu);
                         double* Y = W + (dsc.x >> 16);
                         const d2 dA = ld2(D), dB = ld2(D + 2), y = ld2(Y);
@@ -561,10 +601,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         st2(D, P00, P01); st2(D + 2, P01, P11);
                         st2(Y, __builtin_fma(P00, y.x, P01 * y.y), __builtin_fma(P01, y.x, P11 * y.y));
                     }
+                    dsc = nxt;
                 }
+                PT_MARK(5)
                 for (int p = npu + npi; p < npass; ++p) {    // y_i -= P_i * W' * x_a
-                    if (rlane < C.pass_ntask[p]) {
-                        const uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[p][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    if ((dsc.x & 0xffffu) != 0xffffu) {
                         double* Yi = W + (dsc.x & 0xffffu);
                         const double* Wk = W + (dsc.x >> 16);
                         const double* P = W + (dsc.y & 0xffffu);
@@ -575,7 +617,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         y.x -= __builtin_fma(p0.x, u0, p0.y * u1); y.y -= __builtin_fma(p1.x, u0, p1.y * u1);
                         st2(Yi, y.x, y.y);
                     }
+                    dsc = nxt;
                 }
+                PT_MARK(5)
 #endif
                 RELOAD_FENCE();
                 // ---- step lengths ---------------------------------------------------------------------
@@ -591,25 +635,25 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 // Two passes over the slack/multiplier steps: pass 1 only finds the step lengths (ratio
                 // tests), pass 2 recomputes dz, dmu and applies them.  Recomputing ~150 VALU instructions
                 // keeps 72 VGPRs free, which is what lets two wavefronts share a SIMD.
-                double rp = DINF, rd = DINF;
+                double tp = 0.0, td = 0.0;        // max over inequality rows of -dz/z and -dmu/mu
                 double dF[LS], dG[LS];
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     dF[s] = 0; dG[s] = 0;
-                    if (l_on[s]) {
+                    if (L_ON(s)) {
                         const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
                         const d2 xf = ld2(X + 2 * f), xt = ld2(X + 2 * t);
                         dF[s] = lb(s) * (xf.x - xt.x);
                         dG[s] = lb(s) * (xf.y - xt.y);
-                        if (l_act[s]) {
+                        if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
-                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
-                            if (dzp < 0.0) rp = __builtin_fmin(rp, lzp[s] * frcp(-dzp));
-                            if (dzm < 0.0) rp = __builtin_fmin(rp, lzm[s] * frcp(-dzm));
-                            if (dmup < 0.0) rd = __builtin_fmin(rd, lmup[s] * frcp(-dmup));
-                            if (dmum < 0.0) rd = __builtin_fmin(rd, lmum[s] * frcp(-dmum));
+                            const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
+                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
+                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
+                            // ratio tests without divisions by the steps: min_k z_k/(-dz_k) = 1 / max_k(-dz_k/z_k)
+                            tp = __builtin_fmax(tp, __builtin_fmax(-dzp * rzp, -dzm * rzm));
+                            td = __builtin_fmax(td, __builtin_fmax(-dmup * frcp1(lmup[s]), -dmum * frcp1(lmum[s])));
                         }
                     }
                     SLOT_FENCE();
@@ -619,18 +663,17 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 for (int s = 0; s < IS; ++s) {
                     const int j = 16 * s + rlane;
                     dpv[s] = 0; dlb[s] = 0;
-                    if (i_on[s]) {
+                    if (I_ON(s)) {
                         dlb[s] = X[2 * (iinfo[s] & 0xff) + 1];
-                        if (i_box[s]) {
+                        if (I_BOX(s)) {
                             dpv[s] = __builtin_fma(dlb[s], Stash[16 * (2 * s)], -Stash[16 * (2 * s + 1)]);   // dp = (-Np + dlam)/D
                             const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
-                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
-                            if (dzp < 0.0) rp = __builtin_fmin(rp, izp[s] * frcp(-dzp));
-                            if (dzm < 0.0) rp = __builtin_fmin(rp, izm[s] * frcp(-dzm));
-                            if (dmup < 0.0) rd = __builtin_fmin(rd, imup[s] * frcp(-dmup));
-                            if (dmum < 0.0) rd = __builtin_fmin(rd, imum[s] * frcp(-dmum));
+                            const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
+                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
+                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
+                            tp = __builtin_fmax(tp, __builtin_fmax(-dzp * rzp, -dzm * rzm));
+                            td = __builtin_fmax(td, __builtin_fmax(-dmup * frcp1(imup[s]), -dmum * frcp1(imum[s])));
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
@@ -641,14 +684,14 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
-                    rp = row_min(rp); rd = row_min(rd);
-                    alphap = __builtin_fmin(a.xi * rp, 1.0);
-                    alphad = __builtin_fmin(a.xi * rd, 1.0);
+                    tp = row_max(tp); td = row_max(td);
+                    alphap = tp > 0.0 ? __builtin_fmin(a.xi * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
+                    alphad = td > 0.0 ? __builtin_fmin(a.xi * frcp(td), 1.0) : 1.0;
                     double zl = 0.0, fl = 0.0;
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
-                        if (l_on[s]) {
-                            if (l_act[s]) {
+                        if (L_ON(s)) {
+                            if (L_ACT(s)) {
                                 const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                                 const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
                                 const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
@@ -664,8 +707,8 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
-                        if (i_on[s]) {
-                            if (i_box[s]) {
+                        if (I_ON(s)) {
+                            if (I_BOX(s)) {
                                 const int j = 16 * s + rlane;
                                 const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                                 const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
@@ -689,9 +732,11 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     fval = row_sum(fl);
                     if (niq > 0) gamma = a.sigma * zmu / (double)niq;
                 }
+                PT_MARK(6)
             }
         }
 
+        PT_MARK(6)
         // ===== mc_simulation.m:54-99 (dns, noise filters, nodal shed) + nsqMain.m:270 =============
         if (live) {
             double dns = fval + C.total_load;
@@ -723,7 +768,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             }
             if (WRITE_OUT) {
 #pragma unroll
-                for (int s = 0; s < IS; ++s) if (16 * s + rlane < nip) Ip[16 * s + rlane] = shed[s];
+                for (int s = 0; s < IS; ++s) if (16 * s + rlane < nip) IR[4 * (16 * s + rlane)] = shed[s];
                 if (rlane == 0) {
                     a.dns[sidx] = dns;
                     if (a.status) a.status[sidx] = status;
@@ -735,14 +780,15 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         const int i = 16 * t + rlane;
                         if (i < nb) {
                             const int vj = C.b_vinj[i];
-                            a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? Ip[vj] : 0.0;
+                            a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? IR[4 * vj] : 0.0;
                         }
                     }
                 }
             }
         }
+        PT_MARK(7)
     }
-
+    PT_FLUSH
 }
 
 // device image of relmc_acc (include/relmc.h): 6 + 256 int64, then 2 + 128 doubles
@@ -832,6 +878,7 @@ __global__ void relmc_dpp_probe_kernel(const double* __restrict__ in, double* __
     out[192 + t] = row_min(v);
     out[256 + t] = (double)row_or(1u << (t & 15));
     out[320 + t] = frcp(v);
+    { const double r0 = __builtin_amdgcn_rcp(v); out[384 + t] = r0; const double e = __builtin_fma(-v, r0, 1.0); out[448 + t] = __builtin_fma(r0, e, r0); }
 }
 
 }  // namespace relmc
