@@ -26,7 +26,7 @@ def test_dpp_row_semantics(engine):
     import ctypes as C
     rng = np.random.default_rng(0)
     x = rng.uniform(0.5, 3.0, 64)
-    out = np.zeros(384)
+    out = np.zeros(512)
     rc = engine.L.relmc_dpp_probe(engine._h, x.ctypes.data_as(_abi.c_double_p), out.ctypes.data_as(_abi.c_double_p))
     assert rc == 0
     rows = x.reshape(4, 16)
@@ -35,7 +35,8 @@ def test_dpp_row_semantics(engine):
     assert np.array_equal(out[128:192].reshape(4, 16), np.repeat(rows.max(1, keepdims=True), 16, 1))
     assert np.array_equal(out[192:256].reshape(4, 16), np.repeat(rows.min(1, keepdims=True), 16, 1))
     assert np.all(out[256:320] == 65535.0)
-    np.testing.assert_allclose(out[320:384], 1.0 / x, rtol=4e-16)
+    np.testing.assert_allclose(out[320:384], 1.0 / x, rtol=4e-16)          # frcp: v_rcp_f64 + 2 Newton steps
+    np.testing.assert_allclose(out[448:512], 1.0 / x, rtol=4e-15)          # frcp1: one Newton step (ratio tests only)
     # every lane of a row must hold the bit-identical reduction (row-uniform control flow relies on it)
     assert np.all(out[64:128].reshape(4, 16) == out[64:128].reshape(4, 16)[:, :1])
 
