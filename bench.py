@@ -107,7 +107,7 @@ def main():
                        "scenarios_per_step_per_gpu": B, "policy": args.policy, "seed": args.seed,
                        "parallelism": f"scenario-index sharding x{world}, 1 all-reduce of relmc_acc per step"},
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": None,
+                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": hbm_traffic_from_profile(B),
                          "kernel": "relmc_eval_kernel<true,false>", "kernel_ms_avg": avg_kernel_s * 1e3,
                          "algorithmic_flop_per_scenario": flop_per_scen, "mean_ipm_iterations": idx["mean_iters"]},
             "indices": {"n": n_total, "edns_mw": idx["edns"], "lole_h_per_yr": idx["lole"], "plc": idx["plc"],
@@ -127,6 +127,23 @@ def main():
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
+
+
+def hbm_traffic_from_profile(batch):
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
+    (profiles/*/pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
+    command, gfx950 correction applied); scaled to this batch.  None if no profile is committed."""
+    import glob
+    best = None
+    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
+        try:
+            with open(f) as fh:
+                t = json.load(fh).get("hbm_traffic")
+            if t:
+                best = t["bytes_per_scenario"] * batch
+        except (OSError, ValueError, KeyError):
+            pass
+    return best
 
 
 def cpu_baseline(case, policy, seed, n_sample):
