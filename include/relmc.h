@@ -191,6 +191,23 @@ void relmc_acc_merge(relmc_acc* dst, const relmc_acc* src);
 void relmc_nsq_indices(const relmc_acc* acc, int32_t nb, int32_t ncomp, double hours_per_year,
                        relmc_indices* out);
 
+/* ---- HL1 copper-sheet non-sequential MC --------------------------- */
+/* Mirrors GeneratingAdequacy/PowerSystemAdequacy.jl:169-208 run_non_sequential_mc(gens, load,
+ * iterations): per iteration one fleet state (unit g is down iff draw < FOR_g, i.e. up iff
+ * rand() >= for_rate, :183-185), available capacity, then the whole hourly load curve is swept:
+ * hours with cap < load and their deficit (:191-197). */
+typedef struct {
+    int64_t n;                /* iterations                                 */
+    double sum_lole;          /* sum over iterations of loss hours          */
+    double sum_eue;           /* sum over iterations of unserved energy MWh */
+    double sum_lole2, sum_eue2;
+} relmc_hl1_acc;
+int32_t relmc_hl1_load(relmc_ctx* ctx, int32_t ngen, const double* capacity_mw, const double* for_rate,
+                       int32_t nhours, const double* hourly_load_mw);
+/* iter_lole / iter_eue: optional host buffers [n] with the per-iteration values (history, :202-204) */
+int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, relmc_hl1_acc* acc,
+                      double* iter_lole_host, double* iter_eue_host);
+
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
 int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);
 

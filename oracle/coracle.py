@@ -48,6 +48,8 @@ def lib():
         L.orc_thresholds.argtypes = [C.POINTER(_abi.CaseDesc), _abi.c_uint32_p]
         L.orc_philox4x32_10.argtypes = [_abi.c_uint32_p, _abi.c_uint32_p, _abi.c_uint32_p]
         L.orc_max_threads.restype = C.c_int32
+        L.orc_hl1_nsq.argtypes = [C.c_int32, dp, dp, C.c_int32, dp, C.c_uint64, C.c_uint64, C.c_int64, dp, dp]
+        L.orc_hl1_nsq.restype = C.c_int32
         _lib = L
     return _lib
 
@@ -105,3 +107,16 @@ class Oracle:
 
     def max_threads(self):
         return int(self.L.orc_max_threads())
+
+
+def hl1_nsq(capacity, for_rate, hourly_load, seed, first_index, n):
+    """Oracle of PowerSystemAdequacy.jl:169-208: per-iteration (loss hours, unserved energy)."""
+    L = lib()
+    cap = np.ascontiguousarray(capacity, dtype=np.float64)
+    forr = np.ascontiguousarray(for_rate, dtype=np.float64)
+    hl = np.ascontiguousarray(hourly_load, dtype=np.float64)
+    lole, eue = np.zeros(n), np.zeros(n)
+    p = lambda a: a.ctypes.data_as(_abi.c_double_p)
+    rc = L.orc_hl1_nsq(cap.size, p(cap), p(forr), hl.size, p(hl), seed, first_index, n, p(lole), p(eue))
+    assert rc == 0
+    return lole, eue

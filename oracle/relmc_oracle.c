@@ -626,6 +626,32 @@ void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours
     for (int k = 0; k < ncomp; ++k) out->comp_importance[k] = a->n_fail ? (double)a->comp_fail[k] / (double)a->n_fail : 0.0;
 }
 
+/* HL1 copper sheet — GeneratingAdequacy/PowerSystemAdequacy.jl:169-208 run_non_sequential_mc, restated:
+ * per iteration sample every unit (up iff rand() >= for_rate, :183-185; here: down iff draw_u32 < floor(FOR*2^32)
+ * of the same counter-based stream), then sweep ALL hourly loads (:191-197). */
+int32_t orc_hl1_nsq(int32_t ngen, const double* cap, const double* for_rate, int32_t nhours, const double* load,
+                    uint64_t seed, uint64_t first_index, int64_t n, double* iter_lole, double* iter_eue)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    for (int64_t i = 0; i < n; ++i) {
+        uint64_t gi = first_index + (uint64_t)i;
+        double cap_avail = 0.0;
+        for (int blk = 0; blk * 4 < ngen; ++blk) {
+            uint32_t ctr[4] = {(uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u}, r[4];
+            philox4x32_10(ctr, key, r);
+            for (int e = 0; e < 4 && blk * 4 + e < ngen; ++e) {
+                double t = floor(for_rate[blk * 4 + e] * 4294967296.0);
+                if (!(r[e] < (uint32_t)t)) cap_avail += cap[blk * 4 + e];
+            }
+        }
+        double lole = 0.0, eue = 0.0;
+        for (int h = 0; h < nhours; ++h)
+            if (cap_avail < load[h]) { lole += 1.0; eue += load[h] - cap_avail; }
+        iter_lole[i] = lole; iter_eue[i] = eue;
+    }
+    return RELMC_OK;
+}
+
 int32_t orc_max_threads(void)
 {
 #ifdef _OPENMP

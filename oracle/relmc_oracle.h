@@ -19,6 +19,8 @@ int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t fir
                            const relmc_solver_opts* opts, int32_t nthreads, int32_t use_memo,
                            relmc_acc* acc_out);
 void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out);
+int32_t orc_hl1_nsq(int32_t ngen, const double* cap, const double* for_rate, int32_t nhours, const double* load,
+                    uint64_t seed, uint64_t first_index, int64_t n, double* iter_lole, double* iter_eue);
 int32_t orc_max_threads(void);
 #ifdef __cplusplus
 }

@@ -22,7 +22,7 @@ EXPORTS = [
     "relmc_case_thresholds", "relmc_mc_sampling", "relmc_mc_sampling_dev",
     "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
-    "relmc_nsq_run",
+    "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
 ]
 
 

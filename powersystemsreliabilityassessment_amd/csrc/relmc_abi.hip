@@ -35,6 +35,8 @@ struct relmc_ctx {
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
     unsigned long long* dtiming = nullptr; int timing_waves = 0;
+    // HL1 copper-sheet model
+    bool has_hl1 = false; Hl1Case* dhl1 = nullptr; double* dsorted = nullptr; double* dsuffix = nullptr; int hl1_hours = 0;
     double last_kernel_ms = 0.0;
     std::string err;
 };
@@ -156,6 +158,10 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
     if (ctx->dcase) (void)hipFree(ctx->dcase);
     if (ctx->dacc) (void)hipFree(ctx->dacc);
+    if (ctx->dhl1) (void)hipFree(ctx->dhl1);
+    if (ctx->dsorted) (void)hipFree(ctx->dsorted);
+    if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
+    if (ctx->dtiming) (void)hipFree(ctx->dtiming);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -388,6 +394,13 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         if (C.b_ninj[i] > maxinj_) maxinj_ = C.b_ninj[i];
     }
     C.maxdeg = (uint16_t)maxdeg; C.maxinj = (uint16_t)maxinj_;
+    {   // is the intact network connected?  (lets the kernel skip the island search when no line is out)
+        std::vector<int> lab(nb); for (int i = 0; i < nb; ++i) lab[i] = i;
+        auto find = [&](int x) { while (lab[x] != x) { lab[x] = lab[lab[x]]; x = lab[x]; } return x; };
+        for (int l = 0; l < nl; ++l) { const int a2 = find(d->br_from[l]), b2 = find(d->br_to[l]); if (a2 != b2) lab[a2] = b2; }
+        int roots = 0; for (int i = 0; i < nb; ++i) if (find(i) == i) roots++;
+        C.base_connected = roots == 1 ? 1 : 0;
+    }
     // Bernoulli thresholds: fail iff draw_u32 < floor(U * 2^32)   (mc_sampling.m:35, strict '<')
     for (int k = 0; k < ncomp; ++k) {
         double t = std::floor(d->unavail[k] * 4294967296.0);
@@ -583,6 +596,70 @@ void relmc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hou
     if (ncomp > RELMC_MAX_COMP) ncomp = RELMC_MAX_COMP;
     for (int i = 0; i < nb; ++i) out->nodal_eens[i] = a->sum_nodal[i] / N;
     for (int k = 0; k < ncomp; ++k) out->comp_importance[k] = a->n_fail ? (double)a->comp_fail[k] / (double)a->n_fail : 0.0;
+}
+
+// ---- HL1 copper sheet: PowerSystemAdequacy.jl:169-208 --------------------------------------------------
+int32_t relmc_hl1_load(relmc_ctx* ctx, int32_t ngen, const double* capacity_mw, const double* for_rate, int32_t nhours,
+                       const double* hourly_load_mw)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!capacity_mw || !for_rate || !hourly_load_mw || ngen < 1 || nhours < 1) return fail(ctx, RELMC_ERR_INVALID, "relmc_hl1_load: bad arguments");
+    if (ngen > NCOMPMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_hl1_load: more than 128 units");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Hl1Case h; std::memset(&h, 0, sizeof(h));
+    h.ngen = ngen; h.nhours = nhours;
+    for (int g = 0; g < ngen; ++g) {
+        double t = std::floor(for_rate[g] * 4294967296.0);
+        if (!(t > 0)) t = 0;
+        if (t > 4294967295.0) t = 4294967295.0;
+        h.thr[g] = (uint32_t)t; h.cap[g] = capacity_mw[g];
+    }
+    std::vector<double> sorted(hourly_load_mw, hourly_load_mw + nhours), suffix(nhours + 1, 0.0);
+    std::sort(sorted.begin(), sorted.end());
+    for (int k = nhours - 1; k >= 0; --k) suffix[k] = suffix[k + 1] + sorted[k];
+    if (ctx->dsorted) (void)hipFree(ctx->dsorted);
+    if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
+    ctx->dsorted = ctx->dsuffix = nullptr;
+    if (!ctx->dhl1) HIP_TRY(ctx, hipMalloc(&ctx->dhl1, sizeof(Hl1Case)));
+    HIP_TRY(ctx, hipMalloc(&ctx->dsorted, sizeof(double) * nhours));
+    HIP_TRY(ctx, hipMalloc(&ctx->dsuffix, sizeof(double) * (nhours + 1)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dhl1, &h, sizeof(h), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dsorted, sorted.data(), sizeof(double) * nhours, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dsuffix, suffix.data(), sizeof(double) * (nhours + 1), hipMemcpyHostToDevice));
+    ctx->hl1_hours = nhours; ctx->has_hl1 = true;
+    return RELMC_OK;
+}
+
+int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, relmc_hl1_acc* acc, double* iter_lole_host,
+                      double* iter_eue_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_hl1) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_hl1_nsq: relmc_hl1_load has not been called");
+    if (n < 0 || !acc) return fail(ctx, RELMC_ERR_INVALID, "relmc_hl1_nsq: bad arguments");
+    std::memset(acc, 0, sizeof(*acc));
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
+    double *dl = nullptr, *de = nullptr, *dpart = nullptr;
+    int rc = RELMC_OK;
+    auto cleanup = [&]() { (void)hipFree(dl); (void)hipFree(de); (void)hipFree(dpart); };
+    if ((iter_lole_host && hipMalloc(&dl, sizeof(double) * n) != hipSuccess) || (iter_eue_host && hipMalloc(&de, sizeof(double) * n) != hipSuccess) ||
+        hipMalloc(&dpart, sizeof(double) * 4 * blocks) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: device allocation failed"); }
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    hipLaunchKernelGGL(relmc_hl1_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->dhl1, ctx->dsorted, ctx->dsuffix, seed,
+                       first_index, n, dl, de, dpart);
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    std::vector<double> part((size_t)4 * blocks);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, sizeof(double) * 4 * blocks, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        finish_timing(ctx) != RELMC_OK) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: launch failed");
+    if (rc == RELMC_OK && iter_lole_host && hipMemcpy(iter_lole_host, dl, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    if (rc == RELMC_OK && iter_eue_host && hipMemcpy(iter_eue_host, de, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    cleanup();
+    if (rc) return rc;
+    acc->n = n;
+    for (int64_t b = 0; b < blocks; ++b) { acc->sum_lole += part[4 * b]; acc->sum_eue += part[4 * b + 1]; acc->sum_lole2 += part[4 * b + 2]; acc->sum_eue2 += part[4 * b + 3]; }
+    return RELMC_OK;
 }
 
 // nsqMain.m:208-318: batches until beta <= beta_limit or max_samples, then the post-processing of :345-376

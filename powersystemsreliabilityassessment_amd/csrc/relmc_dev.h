@@ -42,7 +42,7 @@ struct DevCase {
     uint32_t nws;                   // doubles in W
     uint16_t off_rhs, off_p;
     uint16_t npass, npass_upd, npass_inv, nzero;
-    uint16_t maxdeg, maxinj, pad1, pad2;   // largest number of lines / injections at one bus
+    uint16_t maxdeg, maxinj, base_connected, pad2;   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
     uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), 0x7f = none
     uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0x7f = none
     // lines

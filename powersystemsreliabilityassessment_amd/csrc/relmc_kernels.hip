@@ -269,14 +269,21 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             // reference consumes the start point (mc_simulation.m:41,54)
             singular = (a.policy == 0) && iso_any;
 
+            // lines out in this scenario?  If not (95 % of the scenarios) the network is one island and the
+            // reachability sweeps are skipped; the island rules still run on it.
+            bool lout = false;
+#pragma unroll
+            for (int s = 0; s < LS; ++s) lout = lout || (((linfo[s] >> 24) & LF_EXISTS) && !L_ON(s));
+            const bool any_lout = C.base_connected == 0 || ((__ballot(lout) >> (lane & 48)) & 0xffffull) != 0;
             if (!singular) {
                 uint32_t remaining = C.exist_mask;
                 for (int guard = 0; guard < NBT; ++guard) {
                     const bool more = remaining != 0;
                     if (!__any(more)) break;
                     if (more) {
-                        uint32_t R = 1u << (__ffs((int)remaining) - 1);
+                        uint32_t R = any_lout ? 1u << (__ffs((int)remaining) - 1) : remaining;
                         for (int sweep = 0; sweep < NBT; ++sweep) {
+                            if (!__any(any_lout)) break;
                             uint32_t c = 0;
 #pragma unroll
                             for (int t = 0; t < BS; ++t) if ((R >> (16 * t + rlane)) & 1u) c |= adjm[t];
@@ -536,13 +543,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 
                 PT_MARK(2)
                 // ---- convergence test (mips.m feascond/gradcond/compcond/costcond) --------------
-                mx_gh = row_max(mx_gh); mx_x = row_max(mx_x); mx_z = row_max(mx_z);
-                mx_lx = row_max(mx_lx); mx_lammu = row_max(mx_lammu);
+                // The four conditions must hold together, so the two that need only |x| (complementarity and
+                // cost change) are tested first; the other three row reductions run only when some scenario
+                // of the wavefront passes them (never before the last 2-3 iterations).
+                mx_x = row_max(mx_x);
                 const uint64_t nanb = __ballot(nanx);
                 const bool xnan = ((nanb >> (lane & 48)) & 0xffffull) != 0;
-                // feascond < feastol etc. with the (positive) denominators multiplied out
-                const bool conv = it > 0 && mx_gh < a.feastol * (1.0 + __builtin_fmax(mx_x, mx_z)) && mx_lx < a.gradtol * (1.0 + mx_lammu) &&
-                                  zmu < a.comptol * (1.0 + mx_x) && __builtin_fabs(fval - f0) < a.costtol * (1.0 + __builtin_fabs(f0));
+                bool conv = it > 0 && zmu < a.comptol * (1.0 + mx_x) && __builtin_fabs(fval - f0) < a.costtol * (1.0 + __builtin_fabs(f0));
+                if (__any(conv)) {
+                    mx_gh = row_max(mx_gh); mx_z = row_max(mx_z); mx_lx = row_max(mx_lx); mx_lammu = row_max(mx_lammu);
+                    // feascond < feastol, gradcond < gradtol with the (positive) denominators multiplied out
+                    conv = conv && mx_gh < a.feastol * (1.0 + __builtin_fmax(mx_x, mx_z)) && mx_lx < a.gradtol * (1.0 + mx_lammu);
+                }
 #ifdef RELMC_ABLATE_FIXIT
                 if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }
                 else if (false) {}
@@ -865,6 +877,47 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCase* __re
             if (k < ncomp) eqstatus[i * ncomp + k] = w[e] < C->thr[k] ? 1 : 0;
         }
     }
+}
+
+// ---- HL1 copper sheet (PowerSystemAdequacy.jl:169-208): one thread per iteration ------------------
+struct Hl1Case {
+    int32_t ngen, nhours;
+    uint32_t thr[NCOMPMAX];          // unit g down iff draw < thr[g]  (up iff rand() >= for_rate)
+    double cap[NCOMPMAX];
+};
+
+// sorted[] = hourly loads ascending, suffix[k] = sum(sorted[k:]); loss hours = #{load > cap}, deficit by suffix sums
+__global__ void __launch_bounds__(256) relmc_hl1_kernel(const Hl1Case* __restrict__ H, const double* __restrict__ sorted,
+                                                        const double* __restrict__ suffix, uint64_t seed, uint64_t first_index,
+                                                        int64_t n, double* __restrict__ iter_lole, double* __restrict__ iter_eue,
+                                                        double* __restrict__ partial)
+{
+    __shared__ double red[4][4];
+    const int ngen = H->ngen, nh = H->nhours;
+    double s_l = 0.0, s_e = 0.0, s_l2 = 0.0, s_e2 = 0.0;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t gi = first_index + (uint64_t)i;
+        double cap = 0.0;
+        for (int blk = 0; blk * 4 < ngen; ++blk) {
+            uint32_t w[4];
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int g = blk * 4 + e; if (g < ngen && !(w[e] < H->thr[g])) cap += H->cap[g]; }
+        }
+        int lo = 0, hi = nh;                          // first index with sorted[idx] > cap  (cap < load, :192)
+        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] > cap) hi = mid; else lo = mid + 1; }
+        const double hours = (double)(nh - lo);
+        const double eue = lo < nh ? suffix[lo] - cap * hours : 0.0;
+        if (iter_lole) iter_lole[i] = hours;
+        if (iter_eue) iter_eue[i] = eue;
+        s_l += hours; s_e += eue; s_l2 = __builtin_fma(hours, hours, s_l2); s_e2 = __builtin_fma(eue, eue, s_e2);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { s_l += __shfl_xor(s_l, off); s_e += __shfl_xor(s_e, off); s_l2 += __shfl_xor(s_l2, off); s_e2 += __shfl_xor(s_e2, off); }
+    const int wv = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) { red[wv][0] = s_l; red[wv][1] = s_e; red[wv][2] = s_l2; red[wv][3] = s_e2; }
+    __syncthreads();
+    if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // probe used by the unit tests: row broadcast / row all-reduce semantics the solver relies on
