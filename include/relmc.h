@@ -208,6 +208,34 @@ int32_t relmc_hl1_load(relmc_ctx* ctx, int32_t ngen, const double* capacity_mw, 
 int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, relmc_hl1_acc* acc,
                       double* iter_lole_host, double* iter_eue_host);
 
+/* ---- sequential HL2 (/root/reference/Montecarlo_seq/) ----------------- */
+/* relmc_seq_load          <- seqmeantime() [MTTF MTTR] (seqmeantime.m:21-36) + the hourly load factors of
+ *                            anloducurve (anloducurve.m:24-88, seqMain.m:67)
+ * relmc_seq_mcsampling    <- seq_mcsampling(reliability_data, Ng, Nl, 1, hours) per year (seq_mcsampling.m:2;
+ *                            every year starts all-up as seqMain.m:91): out[years][hours][ng+nl], 1 = down
+ * relmc_seq_mcsimulation  <- [curt, nodal] = seq_mcsimulation(status, load_scale, ...) (seq_mcsimulation.m:1), batched
+ * relmc_seq_years         <- the body of seqMain.m:85-176 for a range of simulated years, fused on the GPU:
+ *                            chronology -> contingency hours (:97) -> DC-OPF per hour (:112-133) -> annual
+ *                            indices (:160-176, calnlc.m) + the post-processing accumulators (:142-158)     */
+typedef struct {
+    double ens;               /* MWh, seqMain.m:173              */
+    double dlc;               /* loss hours, :169                */
+    double nlc;               /* loss events, :166 (calnlc)      */
+    int64_t n_contingency;    /* hours evaluated, :103           */
+} relmc_seq_year;
+int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, int32_t hours_per_year,
+                       const double* load_factors);
+int32_t relmc_seq_mcsampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t num_years,
+                             uint8_t* state_host);
+int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const double* load_scale_host, int64_t n,
+                               const relmc_solver_opts* opts, double* dns_host, double* nodal_host,
+                               int32_t* status_host, int32_t* iters_host);
+/* acc_out: n = LPs solved, n_fail = loss hours (curtailment > curtail_threshold, seqMain.m:41,144),
+ * comp_fail = component-down counts during loss hours (:155), sum_nodal = nodal MWh over loss hours (:149) */
+int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t n_years,
+                        const relmc_solver_opts* opts, double curtail_threshold, relmc_seq_year* years_out,
+                        relmc_acc* acc_out);
+
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
 int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);
 

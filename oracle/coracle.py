@@ -48,6 +48,13 @@ def lib():
         L.orc_thresholds.argtypes = [C.POINTER(_abi.CaseDesc), _abi.c_uint32_p]
         L.orc_philox4x32_10.argtypes = [_abi.c_uint32_p, _abi.c_uint32_p, _abi.c_uint32_p]
         L.orc_max_threads.restype = C.c_int32
+        L.orc_seq_mcsimulation.argtypes = [C.POINTER(_abi.CaseDesc), u8p, dp, C.c_int64, C.POINTER(_abi.SolverOpts), dp, dp, i32p, i32p, i32p, C.c_int32]
+        L.orc_seq_mcsimulation.restype = C.c_int32
+        L.orc_seq_mcsampling.argtypes = [C.c_int32, dp, dp, C.c_int32, C.c_uint64, C.c_uint64, C.c_int32, u8p]
+        L.orc_seq_mcsampling.restype = C.c_int32
+        L.orc_seq_years.argtypes = [C.POINTER(_abi.CaseDesc), dp, dp, C.c_int32, dp, C.c_uint64, C.c_uint64, C.c_int32,
+                                    C.POINTER(_abi.SolverOpts), C.c_double, C.c_int32, dp, C.POINTER(_abi.Acc)]
+        L.orc_seq_years.restype = C.c_int32
         L.orc_hl1_nsq.argtypes = [C.c_int32, dp, dp, C.c_int32, dp, C.c_uint64, C.c_uint64, C.c_int64, dp, dp]
         L.orc_hl1_nsq.restype = C.c_int32
         _lib = L
@@ -107,6 +114,42 @@ class Oracle:
 
     def max_threads(self):
         return int(self.L.orc_max_threads())
+
+    # ---- sequential track (Montecarlo_seq/) ------------------------------------------------------
+    def seq_mcsampling(self, rel, hours, seed, first_year, num_years):
+        """states[num_years*hours, ncomp] (1 = down), seq_mcsampling.m:35-76 with independent years."""
+        mttf = np.ascontiguousarray(rel[:, 0], dtype=np.float64); mttr = np.ascontiguousarray(rel[:, 1], dtype=np.float64)
+        out = np.zeros((num_years * hours, self.case.ncomp), dtype=np.uint8)
+        rc = self.L.orc_seq_mcsampling(self.case.ncomp, mttf.ctypes.data_as(_abi.c_double_p), mttr.ctypes.data_as(_abi.c_double_p),
+                                       hours, seed, first_year, num_years, out.ctypes.data_as(_abi.c_uint8_p))
+        assert rc == 0
+        return out
+
+    def seq_mcsimulation(self, states, load_scale, policy=_abi.RELMC_REFERENCE_EMULATE, nthreads=1):
+        states = np.ascontiguousarray(states, dtype=np.uint8).reshape(-1, self.case.ncomp)
+        n = states.shape[0]
+        sc = np.ascontiguousarray(np.broadcast_to(np.asarray(load_scale, dtype=np.float64), (n,)))
+        o = _abi.default_solver_opts(policy)
+        dns = np.zeros(n); nodal = np.zeros((n, self.case.nb))
+        status = np.zeros(n, dtype=np.int32); iters = np.zeros(n, dtype=np.int32); relaxed = np.zeros(n, dtype=np.int32)
+        p = lambda a, t: a.ctypes.data_as(t)
+        rc = self.L.orc_seq_mcsimulation(C.byref(self.h.desc), p(states, _abi.c_uint8_p), p(sc, _abi.c_double_p), n, C.byref(o),
+                                         p(dns, _abi.c_double_p), p(nodal, _abi.c_double_p), p(status, _abi.c_int32_p),
+                                         p(iters, _abi.c_int32_p), p(relaxed, _abi.c_int32_p), nthreads)
+        assert rc == 0
+        return dict(dns=dns, nodal=nodal, status=status, iters=iters, relaxed=relaxed)
+
+    def seq_years(self, rel, hours, load_factors, seed, first_year, n_years, policy=_abi.RELMC_REFERENCE_EMULATE,
+                  threshold=0.01, nthreads=None):
+        mttf = np.ascontiguousarray(rel[:, 0], dtype=np.float64); mttr = np.ascontiguousarray(rel[:, 1], dtype=np.float64)
+        lf = np.ascontiguousarray(load_factors, dtype=np.float64)
+        o = _abi.default_solver_opts(policy)
+        yrs = np.zeros((n_years, 4)); acc = _abi.Acc()
+        rc = self.L.orc_seq_years(C.byref(self.h.desc), mttf.ctypes.data_as(_abi.c_double_p), mttr.ctypes.data_as(_abi.c_double_p), hours,
+                                  lf.ctypes.data_as(_abi.c_double_p), seed, first_year, n_years, C.byref(o), threshold,
+                                  nthreads or self.L.orc_max_threads(), yrs.ctypes.data_as(_abi.c_double_p), C.byref(acc))
+        assert rc == 0
+        return yrs, acc
 
 
 def hl1_nsq(capacity, for_rate, hourly_load, seed, first_index, n):

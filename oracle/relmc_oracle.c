@@ -206,11 +206,12 @@ static int uf_find(int* p, int a) { while (p[a] != a) { p[a] = p[p[a]]; a = p[a]
 
 typedef struct { int singular; int n_relaxed; } pre_info;
 
-static pre_info preprocess(const relmc_case_desc* c, const uint8_t* st, int policy, orc_ws* w)
+static pre_info preprocess(const relmc_case_desc* c, const uint8_t* st, int policy, double scale, orc_ws* w)
 {
     pre_info pi = {0, 0};
     int nb = c->nb, ng = c->ng, nl = c->nl, ninj = c->ng + c->nd;
-    for (int j = 0; j < ninj; ++j) { w->inj_on[j] = j < ng ? !st[j] : 1; w->pmin[j] = c->inj_pmin[j]; }
+    /* seq_mcsimulation.m:38-39: the virtual generators' Pmin (= -load) is scaled by the hourly load factor */
+    for (int j = 0; j < ninj; ++j) { w->inj_on[j] = j < ng ? !st[j] : 1; w->pmin[j] = j < ng ? c->inj_pmin[j] : c->inj_pmin[j] * scale; }
     for (int i = 0; i < nb; ++i) { w->lab[i] = i; w->deg[i] = 0; w->pin[i] = 0; w->drop[i] = 0; }
     for (int l = 0; l < nl; ++l) {
         w->br_on[l] = !st[ng + l];
@@ -234,7 +235,7 @@ static pre_info preprocess(const relmc_case_desc* c, const uint8_t* st, int poli
 #define IN_ISLAND(j) (w->inj_on[j] && w->lab[c->inj_bus[j]] == root)
         for (int j = 0; j < ninj; ++j)
             if (IN_ISLAND(j)) {
-                n_inj++; lo_sum += c->inj_pmin[j];
+                n_inj++; lo_sum += w->pmin[j];
                 if (j >= ng) n_load++; else if (c->inj_pmax[j] > 0) n_gen++;
             }
         if (n_inj && !n_load) {          /* rule 2: island without load: decommit its generators */
@@ -262,32 +263,32 @@ static void add_ae(orc_ws* w, int row, int idx, double val)
     w->ae_idx[row * w->rw + n] = idx; w->ae_val[row * w->rw + n] = val;
 }
 
-static void finish(const relmc_case_desc* c, const orc_ws* w, int ncol, double f, double* dns_out,
+static void finish(const relmc_case_desc* c, const orc_ws* w, int ncol, double f, double scale, double* dns_out,
                    double* nodal)
 {
     /* mc_simulation.m:54-59 */
-    double dns = f + c->total_load;
+    double dns = f + c->total_load * scale;      /* mc_simulation.m:54 / seq_mcsimulation.m:42,67 */
     if (dns < 0.1) dns = 0.0;
     for (int i = 0; i < c->nb; ++i) nodal[i] = 0.0;
     if (dns > 0) {                       /* mc_simulation.m:65 */
         for (int col = 0; col < ncol; ++col) {
             int j = w->inj_of_col[col];
             if (j < c->ng) continue;
-            double shed = w->x[c->nb + col] * c->base_mva - c->inj_pmin[j];   /* Pg - Pmin, :86 */
+            double shed = w->x[c->nb + col] * c->base_mva - c->inj_pmin[j] * scale;   /* Pg - Pmin, :86 */
             if (shed > 1e-3) nodal[c->inj_bus[j]] = shed;                      /* :90-97 */
         }
     }
     *dns_out = dns;
 }
 
-static void solve_state(const relmc_case_desc* c, const uint8_t* st, const relmc_solver_opts* o,
+static void solve_state(const relmc_case_desc* c, const uint8_t* st, double scale, const relmc_solver_opts* o,
                         orc_ws* w, double* dns, double* nodal, int32_t* status, int32_t* iters,
                         int32_t* relaxed)
 {
     const int nb = c->nb, nl = c->nl, ninj = c->ng + c->nd;
     const double base = c->base_mva;
     const double eps = 2.220446049250313e-16;
-    pre_info pi = preprocess(c, st, o->singular_policy, w);
+    pre_info pi = preprocess(c, st, o->singular_policy, scale, w);
     *relaxed = pi.n_relaxed;
 
     /* ---- variables: x = [Va(nb); Pg of in-service injections] (ext2int drops the rest) */
@@ -316,7 +317,7 @@ static void solve_state(const relmc_case_desc* c, const uint8_t* st, const relmc
          * iteration 1 ("numerically failed") and returns x0 */
         double f = 0;
         for (int k = 0; k < nx; ++k) { w->x[k] = w->x0[k]; f += w->c[k] * w->x0[k]; }
-        finish(c, w, ncol, f, dns, nodal);
+        finish(c, w, ncol, f, scale, dns, nodal);
         *status = RELMC_ST_SINGULAR; *iters = 0;
         return;
     }
@@ -470,7 +471,7 @@ static void solve_state(const relmc_case_desc* c, const uint8_t* st, const relmc
 #undef EVAL_H
 #undef EVAL_G
 #undef EVAL_LX
-    finish(c, w, ncol, f, dns, nodal);
+    finish(c, w, ncol, f, scale, dns, nodal);
     *status = converged ? RELMC_ST_CONVERGED : (eflag == -1 ? RELMC_ST_NUMFAIL : RELMC_ST_MAXIT);
     *iters = it;
 }
@@ -478,9 +479,9 @@ static void solve_state(const relmc_case_desc* c, const uint8_t* st, const relmc
 /* ------------------------------------------------------------------------------------ */
 /* public oracle entry points                                                            */
 /* ------------------------------------------------------------------------------------ */
-int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64_t n,
-                          const relmc_solver_opts* opts, double* dns, double* nodal,
-                          int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads)
+int32_t orc_seq_mcsimulation(const relmc_case_desc* c, const uint8_t* states, const double* load_scale, int64_t n,
+                             const relmc_solver_opts* opts, double* dns, double* nodal,
+                             int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads)
 {
     int ncomp = c->ng + c->nl;
     if (c->nb > RELMC_MAX_BUS || ncomp > RELMC_MAX_COMP) return RELMC_ERR_UNSUPPORTED;
@@ -492,7 +493,7 @@ int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64
 #pragma omp for schedule(dynamic, 16)
         for (int64_t i = 0; i < n; ++i) {
             double d; int32_t s, it, rx;
-            solve_state(c, states + i * ncomp, opts, w, &d, nd, &s, &it, &rx);
+            solve_state(c, states + i * ncomp, load_scale ? load_scale[i] : 1.0, opts, w, &d, nd, &s, &it, &rx);
             dns[i] = d;
             if (nodal) memcpy(nodal + i * c->nb, nd, sizeof(double) * c->nb);
             if (status) status[i] = s;
@@ -501,6 +502,99 @@ int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64
         }
         ws_free(w);
     }
+    return RELMC_OK;
+}
+
+int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64_t n,
+                          const relmc_solver_opts* opts, double* dns, double* nodal,
+                          int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads)
+{
+    return orc_seq_mcsimulation(c, states, NULL, n, opts, dns, nodal, status, iters, relaxed, nthreads);
+}
+
+/* seq_mcsampling.m:35-76 for independent years (seqMain.m:91 calls it with num_years = 1, every year starts
+ * all-up): TTF = round(-MTTF ln U), TTR = ceil(-MTTR ln U); U of event e of component k in global year y =
+ * (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key = seed)[e & 3] + 0.5) / 2^32.
+ * out[num_years][hpy][ncomp], 1 = down. */
+int32_t orc_seq_mcsampling(int32_t ncomp, const double* mttf, const double* mttr, int32_t hpy, uint64_t seed,
+                           uint64_t first_year, int32_t num_years, uint8_t* out)
+{
+    uint32_t key[2] = {(uint32_t)seed, (uint32_t)(seed >> 32)};
+    memset(out, 0, (size_t)num_years * hpy * ncomp);
+    for (int y = 0; y < num_years; ++y) {
+        uint64_t gy = first_year + (uint64_t)y;
+        for (int k = 0; k < ncomp; ++k) {
+            long long current = 0; int up = 1; uint32_t r[4];
+            for (int ev = 0; current < hpy; ++ev) {
+                if ((ev & 3) == 0) {
+                    uint32_t ctr[4] = {(uint32_t)gy, (uint32_t)(gy >> 32), (uint32_t)k | 0x80000000u, (uint32_t)(ev >> 2)};
+                    philox4x32_10(ctr, key, r);
+                }
+                double u = ((double)r[ev & 3] + 0.5) * 2.3283064365386963e-10;
+                if (up) {
+                    current += (long long)floor(-mttf[k] * log(u) + 0.5);           /* round(), :53 */
+                } else {
+                    long long dur = (long long)ceil(-mttr[k] * log(u));             /* ceil(), :60 */
+                    long long end = current + dur - 1;
+                    if (end > hpy - 1) end = hpy - 1;
+                    for (long long h = current; h <= end; ++h) out[((size_t)y * hpy + (size_t)h) * ncomp + k] = 1;   /* :63-68 */
+                    current += dur;
+                }
+                up = !up;
+            }
+        }
+    }
+    return RELMC_OK;
+}
+
+/* seqMain.m:85-176 for years [first_year, first_year + n_years): years_out[y] = {ens, dlc, nlc, n_contingency};
+ * acc: n = LPs, n_fail = loss hours, comp_fail = component-down counts during loss, sum_nodal = nodal MWh */
+int32_t orc_seq_years(const relmc_case_desc* c, const double* mttf, const double* mttr, int32_t hpy, const double* load_factors,
+                      uint64_t seed, uint64_t first_year, int32_t n_years, const relmc_solver_opts* opts, double threshold,
+                      int32_t nthreads, double* years_out, relmc_acc* acc)
+{
+    int ncomp = c->ng + c->nl;
+    if (nthreads < 1) nthreads = 1;
+    memset(acc, 0, sizeof(*acc));
+    uint8_t* states = (uint8_t*)xm((size_t)hpy * ncomp);
+    double* curt = (double*)xm(sizeof(double) * hpy);
+    double* nod = (double*)xm(sizeof(double) * (size_t)hpy * c->nb);
+    int32_t* stat = (int32_t*)xm(sizeof(int32_t) * hpy); int32_t* its = (int32_t*)xm(sizeof(int32_t) * hpy); int32_t* rlx = (int32_t*)xm(sizeof(int32_t) * hpy);
+    int* hours = (int*)xm(sizeof(int) * hpy);
+    uint8_t* cst = (uint8_t*)xm((size_t)hpy * ncomp);
+    double* csc = (double*)xm(sizeof(double) * hpy);
+    for (int y = 0; y < n_years; ++y) {
+        orc_seq_mcsampling(ncomp, mttf, mttr, hpy, seed, first_year + (uint64_t)y, 1, states);
+        int nc = 0;
+        for (int h = 0; h < hpy; ++h) {                                    /* contingency hours, :97 */
+            int any = 0;
+            for (int k = 0; k < ncomp; ++k) any |= states[(size_t)h * ncomp + k];
+            if (any) { memcpy(cst + (size_t)nc * ncomp, states + (size_t)h * ncomp, ncomp); csc[nc] = load_factors[h]; hours[nc++] = h; }
+        }
+        orc_seq_mcsimulation(c, cst, csc, nc, opts, curt, nod, stat, its, rlx, nthreads);   /* :112-133 */
+        double* prof = (double*)xm(sizeof(double) * hpy);
+        double ens = 0, dlc = 0, nlc = 0;
+        for (int j = 0; j < nc; ++j) {
+            prof[hours[j]] = curt[j];
+            acc->n += 1; acc->sum_iters += its[j]; acc->sum_dns += curt[j]; acc->sum_dns2 += curt[j] * curt[j];
+            if (stat[j] == RELMC_ST_SINGULAR) acc->n_singular += 1;
+            if (stat[j] == RELMC_ST_MAXIT || stat[j] == RELMC_ST_NUMFAIL) acc->n_nonconverged += 1;
+            if (rlx[j]) acc->n_infeasible += 1;
+            if (curt[j] > threshold) {                                      /* loss hour, :144-158 */
+                acc->n_fail += 1;
+                for (int i = 0; i < c->nb; ++i) acc->sum_nodal[i] += nod[(size_t)j * c->nb + i];
+                for (int k = 0; k < ncomp; ++k) acc->comp_fail[k] += cst[(size_t)j * ncomp + k];
+            }
+        }
+        for (int h = 0; h < hpy; ++h) {                                    /* :136-176, calnlc.m:22-32 */
+            int f = prof[h] > threshold;
+            ens += prof[h];
+            if (f) { dlc += 1; if (h == 0 || !(prof[h - 1] > threshold)) nlc += 1; }
+        }
+        free(prof);
+        years_out[4 * y] = ens; years_out[4 * y + 1] = dlc; years_out[4 * y + 2] = nlc; years_out[4 * y + 3] = nc;
+    }
+    free(states); free(curt); free(nod); free(stat); free(its); free(rlx); free(hours); free(cst); free(csc);
     return RELMC_OK;
 }
 
@@ -589,12 +683,12 @@ int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t fir
                 for (int k = 0; k < ncomp; ++k) if (st[k]) key[k >> 6] |= 1ULL << (k & 63);
                 memo_ent* e = memo_find(&memo, key);
                 if (!e->used) {
-                    solve_state(c, st, opts, w, &e->dns, e->nodal, &e->status, &e->iters, &e->relaxed);
+                    solve_state(c, st, 1.0, opts, w, &e->dns, e->nodal, &e->status, &e->iters, &e->relaxed);
                     e->used = 1; memo.n++;
                 }
                 acc_add(&part[tid], c, st, e->dns, e->nodal, e->status, e->iters, e->relaxed);
             } else {
-                solve_state(c, st, opts, w, &d, nd, &s, &it, &rx);
+                solve_state(c, st, 1.0, opts, w, &d, nd, &s, &it, &rx);
                 acc_add(&part[tid], c, st, d, nd, s, it, rx);
             }
         }

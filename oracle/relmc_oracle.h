@@ -19,6 +19,14 @@ int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t fir
                            const relmc_solver_opts* opts, int32_t nthreads, int32_t use_memo,
                            relmc_acc* acc_out);
 void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out);
+int32_t orc_seq_mcsimulation(const relmc_case_desc* c, const uint8_t* states, const double* load_scale, int64_t n,
+                             const relmc_solver_opts* opts, double* dns, double* nodal,
+                             int32_t* status, int32_t* iters, int32_t* relaxed, int32_t nthreads);
+int32_t orc_seq_mcsampling(int32_t ncomp, const double* mttf, const double* mttr, int32_t hpy, uint64_t seed,
+                           uint64_t first_year, int32_t num_years, uint8_t* out);
+int32_t orc_seq_years(const relmc_case_desc* c, const double* mttf, const double* mttr, int32_t hpy, const double* load_factors,
+                      uint64_t seed, uint64_t first_year, int32_t n_years, const relmc_solver_opts* opts, double threshold,
+                      int32_t nthreads, double* years_out, relmc_acc* acc);
 int32_t orc_hl1_nsq(int32_t ngen, const double* cap, const double* for_rate, int32_t nhours, const double* load,
                     uint64_t seed, uint64_t first_index, int64_t n, double* iter_lole, double* iter_eue);
 int32_t orc_max_threads(void);

@@ -23,6 +23,7 @@ EXPORTS = [
     "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
+    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years",
 ]
 
 

@@ -35,6 +35,8 @@ struct relmc_ctx {
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
     unsigned long long* dtiming = nullptr; int timing_waves = 0;
+    // sequential track
+    bool has_seq = false; SeqCase hseq; SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
     bool has_hl1 = false; Hl1Case* dhl1 = nullptr; double* dsorted = nullptr; double* dsuffix = nullptr; int hl1_hours = 0;
     double last_kernel_ms = 0.0;
@@ -65,6 +67,7 @@ EvalArgs make_args(const relmc_solver_opts& o)
     a.policy = o.singular_policy; a.max_it = o.max_it;
     a.feastol = o.feastol; a.gradtol = o.gradtol; a.comptol = o.comptol; a.costtol = o.costtol;
     a.xi = o.xi; a.sigma = o.sigma; a.z0 = o.z0; a.alpha_min = o.alpha_min; a.max_stepsize = o.max_stepsize;
+    a.fail_threshold = 1e-4;                 // nsqMain.m:270
     return a;
 }
 
@@ -87,7 +90,7 @@ int ensure_partial(relmc_ctx* ctx, int blocks)
     return RELMC_OK;
 }
 
-template <bool FROM_RNG, bool WRITE_OUT>
+template <int MODE>
 int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
 {
     const int blocks = grid_for(ctx, a.n);
@@ -103,7 +106,7 @@ int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
     a.timing = nullptr;
 #endif
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL((relmc_eval_kernel<FROM_RNG, WRITE_OUT>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
+    hipLaunchKernelGGL((relmc_eval_kernel<MODE>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
     *blocks_out = blocks;
@@ -159,6 +162,8 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dcase) (void)hipFree(ctx->dcase);
     if (ctx->dacc) (void)hipFree(ctx->dacc);
     if (ctx->dhl1) (void)hipFree(ctx->dhl1);
+    if (ctx->dseq) (void)hipFree(ctx->dseq);
+    if (ctx->dlf) (void)hipFree(ctx->dlf);
     if (ctx->dsorted) (void)hipFree(ctx->dsorted);
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
@@ -420,10 +425,10 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     ctx->lds_bytes = ((case_bytes + 15u) & ~15u) + 4u * WPB * scen * (uint32_t)sizeof(double);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<true, false>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<false, true>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<true, false>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
     ctx->blocks_per_cu = bpc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase, &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
@@ -485,7 +490,7 @@ int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64
     EvalArgs a = make_args(o);
     a.n = n; a.states = states_dev; a.dns = dns_dev; a.nodal = nodal_dev; a.status = status_dev; a.iters = iters_dev;
     int blocks = 0;
-    int rc = launch_eval<false, true>(ctx, a, &blocks);
+    int rc = launch_eval<1>(ctx, a, &blocks);
     if (rc) return rc;
     return finish_timing(ctx);
 }
@@ -540,7 +545,7 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
         EvalArgs a = make_args(o);
         a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
         int blocks = 0;
-        int rc = launch_eval<true, false>(ctx, a, &blocks);
+        int rc = launch_eval<0>(ctx, a, &blocks);
         if (rc) return rc;
         hipLaunchKernelGGL(relmc_finalize_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks * 4 * WPB, ctx->dacc);
         HIP_TRY(ctx, hipGetLastError());
@@ -596,6 +601,161 @@ void relmc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hou
     if (ncomp > RELMC_MAX_COMP) ncomp = RELMC_MAX_COMP;
     for (int i = 0; i < nb; ++i) out->nodal_eens[i] = a->sum_nodal[i] / N;
     for (int k = 0; k < ncomp; ++k) out->comp_importance[k] = a->n_fail ? (double)a->comp_fail[k] / (double)a->n_fail : 0.0;
+}
+
+// ---- sequential HL2: Montecarlo_seq/ ---------------------------------------------------------------------
+int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, int32_t hpy, const double* load_factors)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_load: no case loaded");
+    if (!mttf || !mttr || !load_factors || hpy < 1 || hpy > 65535) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SeqCase& q = ctx->hseq;
+    std::memset(&q, 0, sizeof(q));
+    q.ncomp = ctx->hcase.ncomp; q.hpy = hpy;
+    for (int k = 0; k < q.ncomp; ++k) {
+        if (!(mttf[k] > 0) || !(mttr[k] > 0)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: MTTF / MTTR must be positive");
+        q.mttf[k] = mttf[k]; q.mttr[k] = mttr[k];
+    }
+    if (!ctx->dseq) HIP_TRY(ctx, hipMalloc(&ctx->dseq, sizeof(SeqCase)));
+    if (ctx->dlf) (void)hipFree(ctx->dlf);
+    ctx->dlf = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->dlf, sizeof(double) * hpy));
+    HIP_TRY(ctx, hipMemcpy(ctx->dseq, &q, sizeof(q), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dlf, load_factors, sizeof(double) * hpy, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    ctx->has_seq = true;
+    return RELMC_OK;
+}
+
+namespace {
+// chronology of years [first_year, first_year + n_years) into freshly zeroed device masks
+int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, uint32_t** dmasks_out)
+{
+    const size_t words = (size_t)n_years * ctx->hseq.hpy * 4;
+    uint32_t* dm = nullptr;
+    HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
+    if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
+    const int64_t nthr = (int64_t)n_years * ctx->hseq.ncomp;
+    hipLaunchKernelGGL(relmc_seq_sampling_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dseq, seed, first_year, n_years, dm);
+    if (hipGetLastError() != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: sampling launch failed"); }
+    *dmasks_out = dm;
+    return RELMC_OK;
+}
+}  // namespace
+
+int32_t relmc_seq_mcsampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t num_years, uint8_t* state_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_mcsampling: relmc_seq_load has not been called");
+    if (num_years < 0 || (num_years > 0 && !state_host)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_mcsampling: bad arguments");
+    if (num_years == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* dm = nullptr;
+    int rc = seq_sample(ctx, seed, first_year, num_years, &dm);
+    if (rc) return rc;
+    const int64_t nh = (int64_t)num_years * ctx->hseq.hpy;
+    const size_t bytes = (size_t)nh * ctx->hseq.ncomp;
+    uint8_t* dst = nullptr;
+    if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: allocation failed"); }
+    hipLaunchKernelGGL(relmc_seq_expand_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, dm, nh, ctx->hseq.ncomp, dst);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(state_host, dst, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: kernel / copy failed");
+    (void)hipFree(dm); (void)hipFree(dst);
+    return rc;
+}
+
+int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const double* load_scale_host, int64_t n, const relmc_solver_opts* opts,
+                               double* dns_host, double* nodal_host, int32_t* status_host, int32_t* iters_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_mcsimulation: no case loaded");
+    if (n < 0 || (n > 0 && (!states_host || !dns_host || !load_scale_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_mcsimulation: bad arguments");
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    const int ncomp = ctx->hcase.ncomp, nb = ctx->hcase.nb;
+    uint8_t* dst = nullptr; double *dsc = nullptr, *ddns = nullptr, *dnod = nullptr; int32_t *dstat = nullptr, *dit = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(dsc); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
+    if (hipMalloc(&dst, (size_t)n * ncomp) != hipSuccess || hipMalloc(&dsc, sizeof(double) * n) != hipSuccess || hipMalloc(&ddns, sizeof(double) * n) != hipSuccess ||
+        hipMalloc(&dnod, sizeof(double) * n * nb) != hipSuccess || hipMalloc(&dstat, sizeof(int32_t) * n) != hipSuccess || hipMalloc(&dit, sizeof(int32_t) * n) != hipSuccess) {
+        cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: device allocation failed");
+    }
+    int rc = RELMC_OK;
+    if (hipMemcpy(dst, states_host, (size_t)n * ncomp, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dsc, load_scale_host, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
+        rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: H2D copy failed");
+    if (rc == RELMC_OK) {
+        EvalArgs a = make_args(o);
+        a.fail_threshold = 0.01;               // CURTAIL_THRESHOLD, seqMain.m:41
+        a.n = n; a.states = dst; a.load_scale = dsc; a.dns = ddns; a.nodal = dnod; a.status = dstat; a.iters = dit;
+        int blocks = 0;
+        rc = launch_eval<1>(ctx, a, &blocks);
+        if (rc == RELMC_OK) rc = finish_timing(ctx);
+    }
+    if (rc == RELMC_OK) {
+        bool ok = hipMemcpy(dns_host, ddns, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (nodal_host) ok = ok && hipMemcpy(nodal_host, dnod, sizeof(double) * n * nb, hipMemcpyDeviceToHost) == hipSuccess;
+        if (status_host) ok = ok && hipMemcpy(status_host, dstat, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (iters_host) ok = ok && hipMemcpy(iters_host, dit, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
+        if (!ok) rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: D2H copy failed");
+    }
+    cleanup();
+    return rc;
+}
+
+int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t n_years, const relmc_solver_opts* opts,
+                        double curtail_threshold, relmc_seq_year* years_out, relmc_acc* acc_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_years: relmc_seq_load has not been called");
+    if (n_years < 0 || !acc_out || (n_years > 0 && !years_out)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_years: bad arguments");
+    relmc_acc_zero(acc_out);
+    if (n_years == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    const int hpy = ctx->hseq.hpy;
+    uint32_t* dm = nullptr; uint16_t* dhours = nullptr; uint32_t* dcounts = nullptr; uint32_t* doff = nullptr; double* dcurt = nullptr; double* dyear = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dm); (void)hipFree(dhours); (void)hipFree(dcounts); (void)hipFree(doff); (void)hipFree(dcurt); (void)hipFree(dyear); };
+    int rc = seq_sample(ctx, seed, first_year, n_years, &dm);
+    if (rc) return rc;
+    const size_t nh = (size_t)n_years * hpy;
+    if (hipMalloc(&dhours, nh * sizeof(uint16_t)) != hipSuccess || hipMalloc(&dcounts, sizeof(uint32_t) * n_years) != hipSuccess ||
+        hipMalloc(&doff, sizeof(uint32_t) * (n_years + 1)) != hipSuccess || hipMalloc(&dcurt, nh * sizeof(double)) != hipSuccess ||
+        hipMalloc(&dyear, sizeof(double) * 3 * n_years) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: device allocation failed"); }
+    std::vector<uint32_t> counts(n_years), off(n_years + 1, 0);
+    bool ok = hipMemsetAsync(dcurt, 0, nh * sizeof(double), ctx->stream) == hipSuccess;
+    hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, dhours, dcounts);
+    ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(counts.data(), dcounts, sizeof(uint32_t) * n_years, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: compaction failed"); }
+    for (int y = 0; y < n_years; ++y) { off[y + 1] = off[y] + counts[y]; years_out[y].n_contingency = counts[y]; }
+    const int64_t nlp = off[n_years];
+    double ms = 0.0;
+    if (nlp > 0) {
+        if (hipMemcpyAsync(doff, off.data(), sizeof(uint32_t) * (n_years + 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
+        EvalArgs a = make_args(o);
+        a.fail_threshold = curtail_threshold;
+        a.n = nlp; a.seq_masks = dm; a.seq_offsets = doff; a.seq_hours = dhours; a.load_factors = ctx->dlf; a.curt = dcurt;
+        a.seq_nyears = n_years; a.seq_hpy = hpy;
+        int blocks = 0;
+        rc = launch_eval<2>(ctx, a, &blocks);
+        if (rc) { cleanup(); return rc; }
+        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks * 4 * WPB, ctx->dacc);
+        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
+        rc = finish_timing(ctx);
+        if (rc) { cleanup(); return rc; }
+        ms = ctx->last_kernel_ms;
+    }
+    hipLaunchKernelGGL(relmc_seq_annual_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dcurt, hpy, curtail_threshold, dyear);
+    std::vector<double> yr((size_t)3 * n_years);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yr.data(), dyear, sizeof(double) * 3 * n_years, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: annual indices failed"); }
+    for (int y = 0; y < n_years; ++y) { years_out[y].ens = yr[3 * y]; years_out[y].dlc = yr[3 * y + 1]; years_out[y].nlc = yr[3 * y + 2]; }
+    ctx->last_kernel_ms = ms;
+    cleanup();
+    return RELMC_OK;
 }
 
 // ---- HL1 copper sheet: PowerSystemAdequacy.jl:169-208 --------------------------------------------------

@@ -104,7 +104,11 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define PT_FLUSH
 #endif
 
-template <bool FROM_RNG, bool WRITE_OUT>
+// MODE 0: fused non-sequential path (states from the counter-based sampler, accumulators only)
+// MODE 1: explicit states (+ optional per-scenario load scale), per-scenario results written out
+// MODE 2: sequential path: scenarios = compacted (year, hour) worklist, states from the chronology bit masks,
+//         load scale from the hourly curve, curtailment written to curt[year][hour]
+template <int MODE>
 __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCase* __restrict__ gcase, const EvalArgs a)
 {
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
@@ -165,6 +169,8 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     for (int64_t grp = gwave; grp < ngroups; grp += gstride) {
         const int64_t sidx = grp * 4 + (lane >> 4);
         const bool live = sidx < a.n;
+        double lscale = 1.0;                 // load_scale_factor of seq_mcsimulation.m:38-42 (1 in the non-sequential path)
+        int seq_year = 0, seq_hour = 0;
         RELOAD_FENCE();
 
         // per-scenario state ------------------------------------------------------------
@@ -184,7 +190,8 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         int it = 0, status = 0;
         bool infeas = false, singular = false, iterating = false;
         uint32_t lozero = 0;                 // bit s: lower bound of injection slot s relaxed to 0 (island rules 3, 4)
-#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[16 * (s) + rlane])
+#define ISC(s) ((16 * (s) + rlane >= ng) ? lscale : 1.0)      /* virtual generators (loads) scale with the hourly factor */
+#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[16 * (s) + rlane] * ISC(s))
 #pragma unroll
         for (int s = 0; s < LS; ++s) { LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
 #pragma unroll
@@ -194,7 +201,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 
         if (live) {
             // ===== mc_sampling.m:24-41: Bernoulli outage state (1 = failed) ==================
-            if (FROM_RNG) {
+            if (MODE == 0) {
                 const uint64_t gi = a.first_index + (uint64_t)sidx;
 #pragma unroll
                 for (int h = 0; h < 2; ++h) {
@@ -213,7 +220,17 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     if (h == 0) { if (rlane < 8) o0 |= sh; else o1 |= sh; }
                     else { if (rlane < 8) o2 |= sh; else o3 |= sh; }
                 }
+            } else if (MODE == 2) {
+                // (year, hour) of worklist entry sidx: binary search in the per-year offsets, seqMain.m:97-100
+                int lo_ = 0, hi_ = a.seq_nyears;
+                while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int64_t)a.seq_offsets[mid] <= sidx) lo_ = mid; else hi_ = mid; }
+                seq_year = lo_;
+                seq_hour = a.seq_hours[(size_t)seq_year * a.seq_hpy + (size_t)(sidx - a.seq_offsets[seq_year])];
+                const uint32_t* m = a.seq_masks + ((size_t)seq_year * a.seq_hpy + seq_hour) * 4;
+                o0 = m[0]; o1 = m[1]; o2 = m[2]; o3 = m[3];
+                lscale = a.load_factors[seq_hour];            // seqMain.m:114
             } else {
+                if (a.load_scale) lscale = a.load_scale[sidx];
                 const uint8_t* st = a.states + sidx * ncomp;
 #pragma unroll
                 for (int q = 0; q < NCOMPMAX / 16; ++q) {
@@ -224,7 +241,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     }
                 }
             }
-            o0 = row_or(o0); o1 = row_or(o1); o2 = row_or(o2); o3 = row_or(o3);
+            if (MODE != 2) { o0 = row_or(o0); o1 = row_or(o1); o2 = row_or(o2); o3 = row_or(o3); }
 
             // ===== mc_simulation.m:32-37: component status -> model ==========================
 #pragma unroll
@@ -305,7 +322,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                             if (inI[s]) {
                                 cnt += 1u;
                                 if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
-                                losum += C.i_pmin_mw[j];
+                                losum += C.i_pmin_mw[j] * ISC(s);
                             }
                         }
                         cnt = row_add(cnt); losum = row_sum(losum);
@@ -751,16 +768,16 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         PT_MARK(6)
         // ===== mc_simulation.m:54-99 (dns, noise filters, nodal shed) + nsqMain.m:270 =============
         if (live) {
-            double dns = fval + C.total_load;
+            double dns = fval + C.total_load * lscale;            // mc_simulation.m:54 / seq_mcsimulation.m:67
             if (dns < 0.1) dns = 0.0;
-            const bool fail = dns > 1e-4;
+            const bool fail = dns > a.fail_threshold;             // nsqMain.m:270 (1e-4) / seqMain.m:41,140 (0.01)
             double shed[IS];
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
                 const int j = 16 * s + rlane;
                 shed[s] = 0.0;
                 if (((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL && dns > 0.0) {
-                    const double v = ip[s] * base - C.i_pmin_mw[j];     // Pg - Pmin, mc_simulation.m:86
+                    const double v = ip[s] * base - C.i_pmin_mw[j] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
                 if (shed[s] != 0.0) PA.shed[s] += shed[s];
@@ -778,7 +795,8 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 if (infeas) PA.ninf += 1;
                 PA.iters += (uint32_t)it;
             }
-            if (WRITE_OUT) {
+            if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
+            if (MODE == 1) {
 #pragma unroll
                 for (int s = 0; s < IS; ++s) if (16 * s + rlane < nip) IR[4 * (16 * s + rlane)] = shed[s];
                 if (rlane == 0) {
@@ -877,6 +895,107 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCase* __re
             if (k < ncomp) eqstatus[i * ncomp + k] = w[e] < C->thr[k] ? 1 : 0;
         }
     }
+}
+
+// ---- sequential track (Montecarlo_seq/): chronology sampling, contingency-hour compaction, annual indices ----
+struct SeqCase {
+    int32_t ncomp, hpy;
+    double mttf[NCOMPMAX], mttr[NCOMPMAX];
+};
+
+// seq_mcsampling.m:35-76, one thread per (year, component): alternate TTF = round(-MTTF ln U) and
+// TTR = ceil(-MTTR ln U), every year starts all-up (seqMain.m:91 calls it with num_years = 1).  U of event e of
+// component k in global year y = (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key=seed)[e & 3] + 0.5) / 2^32.
+// Down hours are OR-ed into masks[year][hour][4 x u32] (bit k), which must be zero on entry.
+__global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* __restrict__ Q, uint64_t seed, uint64_t first_year,
+                                                                 int32_t n_years, uint32_t* __restrict__ masks)
+{
+    const int ncomp = Q->ncomp, hpy = Q->hpy;
+    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+    if (t >= (int64_t)n_years * ncomp) return;
+    const int y = (int)(t / ncomp), k = (int)(t - (int64_t)y * ncomp);
+    const uint64_t gy = first_year + (uint64_t)y;
+    const double mttf = Q->mttf[k], mttr = Q->mttr[k];
+    long long current = 0;
+    bool up = true;
+    uint32_t w[4];
+    for (int ev = 0; current < hpy; ++ev) {
+        if ((ev & 3) == 0)
+            philox4x32_10((uint32_t)gy, (uint32_t)(gy >> 32), (uint32_t)k | 0x80000000u, (uint32_t)(ev >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+        const double u = ((double)w[ev & 3] + 0.5) * 2.3283064365386963e-10;   // (0, 1)
+        if (up) {
+            current += (long long)__builtin_floor(-mttf * log(u) + 0.5);        // round(), seq_mcsampling.m:53
+        } else {
+            const long long dur = (long long)__builtin_ceil(-mttr * log(u));    // ceil(), >= 1 h, seq_mcsampling.m:60
+            long long end = current + dur - 1;
+            if (end > hpy - 1) end = hpy - 1;
+            for (long long h = current; h <= end; ++h)
+                atomicOr(&masks[((size_t)y * hpy + (size_t)h) * 4 + (k >> 5)], 1u << (k & 31));
+            current += dur;
+        }
+        up = !up;
+    }
+}
+
+// masks -> uint8 states [years][hours][ncomp] (the materialised seq_mcsampling output)
+__global__ void __launch_bounds__(256) relmc_seq_expand_kernel(const uint32_t* __restrict__ masks, int64_t nhours_total, int ncomp,
+                                                               uint8_t* __restrict__ states)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nhours_total * ncomp; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t h = t / ncomp; const int k = (int)(t - h * ncomp);
+        states[t] = (masks[h * 4 + (k >> 5)] >> (k & 31)) & 1u;
+    }
+}
+
+// seqMain.m:97-100: hours with at least one component down, kept in ascending order (one workgroup per year)
+__global__ void __launch_bounds__(256) relmc_seq_compact_kernel(const uint32_t* __restrict__ masks, int hpy, uint16_t* __restrict__ hours,
+                                                                uint32_t* __restrict__ counts)
+{
+    __shared__ uint32_t wsum[4];
+    __shared__ uint32_t base;
+    const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+    if (tid == 0) base = 0;
+    __syncthreads();
+    for (int h0 = 0; h0 < hpy; h0 += 256) {
+        const int h = h0 + tid;
+        bool f = false;
+        if (h < hpy) { const uint32_t* m = masks + ((size_t)y * hpy + h) * 4; f = (m[0] | m[1] | m[2] | m[3]) != 0; }
+        const uint64_t b = __ballot(f);
+        const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
+        if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
+        __syncthreads();
+        uint32_t off = base;
+        for (int q = 0; q < wv; ++q) off += wsum[q];
+        if (f) hours[(size_t)y * hpy + off + before] = (uint16_t)h;
+        __syncthreads();
+        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
+        __syncthreads();
+    }
+    if (tid == 0) counts[y] = base;
+}
+
+// seqMain.m:136-176 + calnlc.m:22-32: annual loss hours (dlc), loss events (nlc = rising edges of the loss flag,
+// hour 1 counts) and energy not supplied; one workgroup per year, fixed summation order.
+__global__ void __launch_bounds__(256) relmc_seq_annual_kernel(const double* __restrict__ curt, int hpy, double threshold,
+                                                               double* __restrict__ year_out /* [years][3] = ens, dlc, nlc */)
+{
+    __shared__ double red[3][256];
+    const int y = blockIdx.x, tid = threadIdx.x;
+    const double* c = curt + (size_t)y * hpy;
+    double ens = 0.0, dlc = 0.0, nlc = 0.0;
+    for (int h = tid; h < hpy; h += 256) {
+        const double v = c[h];
+        const bool f = v > threshold;
+        ens += v;
+        if (f) { dlc += 1.0; if (h == 0 || !(c[h - 1] > threshold)) nlc += 1.0; }
+    }
+    red[0][tid] = ens; red[1][tid] = dlc; red[2][tid] = nlc;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; red[2][tid] += red[2][tid + off]; }
+        __syncthreads();
+    }
+    if (tid < 3) year_out[(size_t)y * 3 + tid] = red[tid][0];
 }
 
 // ---- HL1 copper sheet (PowerSystemAdequacy.jl:169-208): one thread per iteration ------------------

@@ -16,6 +16,13 @@ Outputs (all small JSON, data only):
                         computed in Python exactly as the reference does it: unique-state
                         database with occurrence counts (nsqMain.m:220-245,269-301).
 
+  seq_golden.json       the reference's golden sequential artifacts
+                        (Montecarlo_seq/seq_reliability_results.mat + seq_nodal_results.csv,
+                        written by seqMain.m:255-262): annual ens/dlc/nlc of the 1245 simulated
+                        years, the cumulative EENS / CoV curves, nodal EENS and importance.
+  seq_hours_fixture.json  scaled-load hours (state, load factor) with the scipy/HiGHS LP value
+                        of seq_mcsimulation.m's scaled model and the numpy MIPS restatement.
+
 Nothing here is read at test time from /root/reference; the JSON files are.
 """
 from __future__ import annotations
@@ -68,6 +75,73 @@ def golden_from_reference(ref):
     with open(os.path.join(HERE, "nsq_golden.json"), "w") as f:
         json.dump(out, f)
     print("nsq_golden.json: EDNS", out["accumulated_edns"], "LOLE", out["accumulated_lole"])
+
+
+def golden_seq_from_reference(ref):
+    import scipy.io as sio
+    m = sio.loadmat(os.path.join(ref, "Montecarlo_seq", "seq_reliability_results.mat"), squeeze_me=True, struct_as_record=False)
+    csv = np.loadtxt(os.path.join(ref, "Montecarlo_seq", "seq_nodal_results.csv"), delimiter=",", skiprows=1)
+    cum, yr = m["results_cum"], m["results_year"]
+    ny = int(np.asarray(cum.eens).size)
+    out = dict(
+        source="Montecarlo_seq/seq_reliability_results.mat + seq_nodal_results.csv (seqMain.m:255-262)",
+        final_year=ny, hours_per_year=8736, cov_threshold=0.05, curtail_threshold=0.01,
+        ens=[float(v) for v in yr.ens[:ny]], dlc=[int(v) for v in yr.dlc[:ny]], nlc=[int(v) for v in yr.nlc[:ny]],
+        cum_eens=[float(v) for v in cum.eens], cum_cov=[float(v) for v in cum.cov],
+        nodal_eens_avg=[float(v) for v in np.asarray(m["nodal_eens_avg"]).ravel()],
+        comp_importance=[float(v) for v in np.asarray(m["comp_importance"]).ravel()],
+        nodal_results_csv_eens_mwh_yr=[float(v) for v in csv[:, 1]],
+    )
+    with open(os.path.join(HERE, "seq_golden.json"), "w") as f:
+        json.dump(out, f)
+    print("seq_golden.json: years", ny, "EENS", out["cum_eens"][-1], "LOLE", float(np.mean(out["dlc"])), "LOLF", float(np.mean(out["nlc"])))
+
+
+def _scaled_case(scale):
+    """seq_mcsimulation.m:38-42: virtual-generator Pmin (= -load) and Pload times the hourly factor."""
+    import dataclasses
+    c = dataclasses.replace(CASE)
+    for name in ("inj_pmin", "inj_lo"):
+        if hasattr(c, name):
+            a = np.array(getattr(c, name), dtype=float).copy()
+            a[CASE.ng:] *= scale
+            setattr(c, name, a)
+    c.total_load = CASE.total_load * scale
+    return c
+
+
+def _eval_scaled(args):
+    idx_list, scale, policy = args
+    c = _scaled_case(scale)
+    st = np.zeros(CASE.ncomp, dtype=np.uint8)
+    st[list(idx_list)] = 1
+    m = po.mips_full(c, st, policy)
+    h = po.lp_highs(c, st, policy)
+    return dict(dns=float(m["dns"]), nodal=[float(v) for v in m["nodal"]], iters=int(m["iters"]), status=int(m["status"]),
+                highs_dns=(None if not h["feasible"] else float(h["dns"])))
+
+
+def seq_hours_fixture(n_hours):
+    """Random (state, load factor) hours: states from the NSQ sampler thinned to the interesting ones
+    plus the SPECIAL list, factors spanning the annual curve's range [0.33, 1]."""
+    th = case24.thresholds_u32(CASE)
+    s = po.mc_sampling(th, 7, 0, 200 * n_hours)
+    rng = np.random.default_rng(7)
+    lists = [list(map(int, np.flatnonzero(u))) for u in s if u.sum() >= 5][:n_hours] + [sorted(x) for x in SPECIAL]
+    scales = [float(x) for x in rng.uniform(0.33, 1.0, len(lists))]
+    for i in range(0, len(lists), 9):
+        scales[i] = 1.0                                            # some at the annual peak
+    with mp.Pool(8) as pool:
+        res0 = pool.map(_eval_scaled, [(l, sc, po.REFERENCE_EMULATE) for l, sc in zip(lists, scales)], chunksize=8)
+        res1 = pool.map(_eval_scaled, [(l, sc, po.PHYSICAL) for l, sc in zip(lists, scales)], chunksize=8)
+    out = dict(description="hour -> oracle results of the scaled-load DC-OPF (seq_mcsimulation.m)", ncomp=CASE.ncomp,
+               hours=[dict(failed=l, load_scale=sc, emulate=a, physical=b) for l, sc, a, b in zip(lists, scales, res0, res1)])
+    with open(os.path.join(HERE, "seq_hours_fixture.json"), "w") as f:
+        json.dump(out, f)
+    bad = [x for x in out["hours"] if x["physical"]["highs_dns"] is not None
+           and abs(x["physical"]["highs_dns"] - x["physical"]["dns"]) > 1e-5]
+    print("seq_hours_fixture.json:", len(lists), "hours; MIPS-vs-HiGHS mismatches:", len(bad),
+          "; loss hours", sum(1 for x in out["hours"] if x["physical"]["dns"] > 0.01))
 
 
 SPECIAL = [
@@ -147,7 +221,12 @@ if __name__ == "__main__":
     ap.add_argument("--reference", default="/root/reference")
     ap.add_argument("--n-states-sample", type=int, default=3000)
     ap.add_argument("--n-nsq", type=int, default=100000)
+    ap.add_argument("--only-seq", action="store_true")
     a = ap.parse_args()
+    golden_seq_from_reference(a.reference)
+    seq_hours_fixture(160)
+    if a.only_seq:
+        sys.exit(0)
     golden_from_reference(a.reference)
     states_fixture(a.n_states_sample)
     nsq_fixture(a.n_nsq)

@@ -1,0 +1,245 @@
+"""Sequential HL2 track (BASELINE config 4): chronology, scaled-load DC-OPF, annual indices.
+
+CPU tests pin the oracle (oracle/relmc_oracle.c orc_seq_*) against a pure-Python restatement of
+seq_mcsampling.m, the HiGHS / numpy-MIPS fixture of seq_mcsimulation.m's scaled model and the reference's own
+golden seq_reliability_results.mat.  GPU tests compare the HIP path (relmc_seq_* through the C ABI) with the oracle.
+"""
+import json
+import math
+import os
+
+import numpy as np
+import pytest
+
+from powersystemsreliabilityassessment_amd import _abi, case24, loadcurve, seq
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+HPY = 8736
+
+
+@pytest.fixture(scope="module")
+def seq_golden():
+    with open(os.path.join(GOLDEN, "seq_golden.json")) as f:
+        return json.load(f)
+
+
+@pytest.fixture(scope="module")
+def hours_fixture(case):
+    with open(os.path.join(GOLDEN, "seq_hours_fixture.json")) as f:
+        d = json.load(f)
+    st = np.zeros((len(d["hours"]), case.ncomp), dtype=np.uint8)
+    for i, x in enumerate(d["hours"]):
+        st[i, x["failed"]] = 1
+    d["matrix"] = st
+    d["scale"] = np.array([x["load_scale"] for x in d["hours"]])
+    return d
+
+
+@pytest.fixture(scope="module")
+def rel():
+    return seq.seqmeantime()
+
+
+@pytest.fixture(scope="module")
+def load_factors():
+    return loadcurve.anloducurve(HPY)[2]
+
+
+def _chronology_py(rel, hpy, seed, year, comps):
+    """seq_mcsampling.m:35-76 restated line by line (one year, all-up start) on the counter-based stream."""
+    from oracle import pyoracle as po
+    out = np.zeros((hpy, rel.shape[0]), dtype=np.uint8)
+    for k in comps:
+        current, up, ev = 0, True, 0
+        while current < hpy:
+            r = po.philox4x32_10(np.array([year & 0xffffffff, year >> 32, k | 0x80000000, ev >> 2], dtype=np.uint32),
+                                 np.array([seed & 0xffffffff, seed >> 32], dtype=np.uint32))
+            u = (float(r[ev & 3]) + 0.5) * 2.0 ** -32
+            if up:
+                current += int(math.floor(-rel[k, 0] * math.log(u) + 0.5))
+            else:
+                dur = int(math.ceil(-rel[k, 1] * math.log(u)))
+                out[current:min(current + dur, hpy), k] = 1
+                current += dur
+            up = not up
+            ev += 1
+    return out
+
+
+# ---------------------------------------------------------------------------------------------- CPU
+def test_seqmeantime_values(case, rel):
+    """seqmeantime.m:21-36: generators keep their MTTF/MTTR, branches get 8760/lambda and r (with the brdur quirk)."""
+    d = case24.case24_failrate()
+    assert rel.shape == (case.ncomp, 2)
+    np.testing.assert_array_equal(rel[:33, 0], d["genmttf"]); np.testing.assert_array_equal(rel[:33, 1], d["genmttr"])
+    np.testing.assert_allclose(rel[33:, 0], 8760.0 / d["brlambda"])
+    assert rel[33 + 10, 0] == pytest.approx(29200.0) and rel[33 + 10, 1] == 10.0          # L11: 0.3 /yr, 10 h
+    assert list(np.flatnonzero(rel[33:, 1] == 768.0) + 1) == [6, 14, 15, 16, 17]           # transformer repair times
+    assert rel[14, 0] == 1e4 and rel[14, 1] == 0.1                                         # synchronous condenser row
+
+
+def test_calnlc():
+    """calnlc.m:22-32."""
+    assert seq.calnlc([0, 0, 0]) == 0
+    assert seq.calnlc([1, 1, 0, 1, 0, 0, 1]) == 3
+    assert seq.calnlc([0, 1, 1, 1]) == 1
+    assert seq.calnlc([]) == 0
+
+
+def test_oracle_chronology_matches_python_restatement(oracle, rel):
+    comps = [0, 5, 14, 22, 32, 33, 38, 43, 70]
+    for year in (0, 3):
+        ref = _chronology_py(rel, HPY, 11, year, comps)
+        got = oracle.seq_mcsampling(rel, HPY, 11, year, 1)
+        np.testing.assert_array_equal(got[:, comps], ref[:, comps])
+    # years are independent streams: sampling [0,3) contains year 2 sampled on its own
+    a = oracle.seq_mcsampling(rel, HPY, 5, 0, 3)
+    b = oracle.seq_mcsampling(rel, HPY, 5, 2, 1)
+    np.testing.assert_array_equal(a[2 * HPY:], b)
+    assert a[0].sum() == 0 and a[HPY].sum() == 0 and a[2 * HPY].sum() == 0                # every year starts all-up
+
+
+def test_oracle_chronology_statistics(oracle, rel):
+    """Down-time fraction ~ E[ceil TTR] / (MTTF + E[ceil TTR]) minus the all-up start transient."""
+    ny = 40
+    s = oracle.seq_mcsampling(rel, HPY, 3, 0, ny).reshape(ny, HPY, -1)
+    frac = s.mean(axis=(0, 1))
+    for k in (0, 8, 22, 32):                      # U12, U76, U400, U350
+        mttr_eff = rel[k, 1] + 0.5                # ceil() adds half an hour on average
+        expect = mttr_eff / (rel[k, 0] + mttr_eff)
+        assert frac[k] == pytest.approx(expect, rel=0.25), k
+    assert frac[14] < 2e-4                        # synchronous condenser: MTTF 1e4 h, MTTR 0.1 h -> 1 h outages, rarely
+    assert 0.6 < (s.sum(axis=2) > 0).mean() < 0.9  # most hours have something down (seqMain's contingency hours)
+
+
+def test_oracle_scaled_lp_vs_highs_and_mips(oracle, hours_fixture):
+    """seq_mcsimulation.m's scaled model: oracle dns = HiGHS optimum (1e-5 MW) and = numpy MIPS in iterations."""
+    for name, pol in (("emulate", _abi.RELMC_REFERENCE_EMULATE), ("physical", _abi.RELMC_PHYSICAL)):
+        r = oracle.seq_mcsimulation(hours_fixture["matrix"], hours_fixture["scale"], pol, nthreads=8)
+        for i, x in enumerate(hours_fixture["hours"]):
+            e = x[name]
+            assert r["status"][i] == e["status"], (name, i)
+            assert r["iters"][i] == e["iters"], (name, i)
+            assert r["dns"][i] == pytest.approx(e["dns"], abs=1e-6), (name, i)
+            if e["highs_dns"] is not None and e["status"] == 0:
+                hd = e["highs_dns"] if e["highs_dns"] >= 0.1 else 0.0
+                assert r["dns"][i] == pytest.approx(hd, abs=2e-5), (name, i)
+    # scale 1 is the non-sequential model
+    a = oracle.seq_mcsimulation(hours_fixture["matrix"][:40], 1.0)
+    b = oracle.mc_simulation(hours_fixture["matrix"][:40])
+    np.testing.assert_array_equal(a["dns"], b["dns"])
+
+
+def test_oracle_year_indices_from_parts(oracle, rel, load_factors):
+    """orc_seq_years = seqMain.m:91-176 assembled from its parts (sampling, contingency hours, OPF, calnlc)."""
+    yrs, acc = oracle.seq_years(rel, HPY, load_factors, 1, 1, 1)
+    st = oracle.seq_mcsampling(rel, HPY, 1, 1, 1)
+    hours = np.flatnonzero(st.sum(1) > 0)                                    # seqMain.m:97
+    r = oracle.seq_mcsimulation(st[hours], load_factors[hours], nthreads=8)
+    prof = np.zeros(HPY); prof[hours] = r["dns"]
+    flag = prof > 0.01                                                       # seqMain.m:141
+    assert yrs[0, 3] == hours.size and acc.n == hours.size
+    assert yrs[0, 0] == pytest.approx(prof.sum(), rel=1e-12)
+    assert yrs[0, 1] == flag.sum() and yrs[0, 2] == seq.calnlc(flag)
+    assert acc.n_fail == flag.sum()
+    np.testing.assert_array_equal(np.array(acc.comp_fail[:71]), st[flag].sum(0))
+    np.testing.assert_allclose(np.array(acc.sum_nodal[:24]), r["nodal"][flag[hours]].sum(0), rtol=1e-12, atol=1e-9)
+
+
+def test_oracle_vs_golden_statistics(oracle, rel, load_factors, seq_golden):
+    """A short oracle run agrees with the reference's golden 1245-year run within sampling error."""
+    g_ens, g_dlc, g_nlc = (np.array(seq_golden[k], dtype=float) for k in ("ens", "dlc", "nlc"))
+    assert seq_golden["final_year"] == 1245
+    assert g_ens.mean() == pytest.approx(seq_golden["cum_eens"][-1], rel=1e-12)
+    assert g_ens.std(ddof=1) / (g_ens.mean() * math.sqrt(1245)) == pytest.approx(seq_golden["cum_cov"][-1], rel=1e-9)
+    ny = 24
+    yrs, acc = oracle.seq_years(rel, HPY, load_factors, 2, 0, ny)
+    for col, g in ((0, g_ens), (1, g_dlc), (2, g_nlc)):
+        se = g.std(ddof=1) * math.sqrt(1.0 / ny + 1.0 / g.size)
+        assert abs(yrs[:, col].mean() - g.mean()) < 4 * se, (col, yrs[:, col].mean(), g.mean())
+    assert acc.n_nonconverged == 0
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+@pytest.fixture(scope="module")
+def seqeng(engine):
+    return seq.SeqEngine(engine)
+
+
+@pytest.mark.gpu
+def test_gpu_chronology_bit_exact(seqeng, oracle, rel):
+    got = seqeng.seq_mcsampling(rel, 33, 38, 3, HPY, seed=9, first_year=5)
+    ref = oracle.seq_mcsampling(rel, HPY, 9, 5, 3)
+    assert got.shape == (71, 3 * HPY)
+    np.testing.assert_array_equal(got.T, ref)
+
+
+@pytest.mark.gpu
+def test_gpu_scaled_hours_parity(seqeng, oracle, hours_fixture):
+    from powersystemsreliabilityassessment_amd import api
+    for name, pol in (("emulate", _abi.RELMC_REFERENCE_EMULATE), ("physical", _abi.RELMC_PHYSICAL)):
+        dns, nodal, info = seqeng.seq_mcsimulation(hours_fixture["matrix"], hours_fixture["scale"], mpopt=api.mpoption(pol), return_info=True)
+        r = oracle.seq_mcsimulation(hours_fixture["matrix"], hours_fixture["scale"], pol, nthreads=8)
+        np.testing.assert_array_equal(info["status"], r["status"])
+        np.testing.assert_array_equal(info["iters"], r["iters"])
+        np.testing.assert_allclose(dns, r["dns"], rtol=0, atol=1e-6)
+        np.testing.assert_allclose(nodal.sum(1), r["nodal"].sum(1), rtol=0, atol=2e-3)     # per-bus split is degenerate
+        for i, x in enumerate(hours_fixture["hours"]):
+            assert dns[i] == pytest.approx(x[name]["dns"], abs=1e-6)
+    d1, n1 = seqeng.seq_mcsimulation(hours_fixture["matrix"][3], hours_fixture["scale"][3])
+    assert isinstance(d1, float) and n1.shape == (24,)
+
+
+@pytest.mark.gpu
+def test_gpu_years_match_oracle(seqeng, oracle, rel, load_factors):
+    ny = 3
+    ens, dlc, nlc, ncont, acc = seqeng.seq_years(4, 10, ny)
+    yrs, oacc = oracle.seq_years(rel, HPY, load_factors, 4, 10, ny)
+    np.testing.assert_array_equal(ncont, yrs[:, 3].astype(np.int64))
+    np.testing.assert_array_equal(dlc, yrs[:, 1]); np.testing.assert_array_equal(nlc, yrs[:, 2])
+    np.testing.assert_allclose(ens, yrs[:, 0], rtol=1e-9, atol=1e-6)
+    assert (acc.n, acc.n_fail, acc.n_singular, acc.n_infeasible, acc.n_nonconverged) == \
+           (oacc.n, oacc.n_fail, oacc.n_singular, oacc.n_infeasible, oacc.n_nonconverged)
+    assert acc.sum_iters == oacc.sum_iters
+    np.testing.assert_array_equal(np.array(acc.comp_fail[:71]), np.array(oacc.comp_fail[:71]))
+    assert sum(acc.sum_nodal[:24]) == pytest.approx(sum(oacc.sum_nodal[:24]), rel=1e-6)
+
+
+@pytest.mark.gpu
+def test_gpu_seqmain_vs_golden(seqeng, seq_golden, tmp_path):
+    """BASELINE config 4: run seqMain to CoV < 5 % and compare with the reference's golden run (1245 years,
+    EENS 4266.87 MWh/yr, LOLE 14.33 h/yr, LOLF 2.465 occ/yr) within sampling error of both runs."""
+    r = seqeng.seqMain(seed=1)
+    g_ens, g_dlc, g_nlc = (np.array(seq_golden[k], dtype=float) for k in ("ens", "dlc", "nlc"))
+    assert 0 < r.cov < 0.05 and 300 < r.final_year < 4000
+    assert r.results_cum["cov"][-2] >= 0.05 or r.final_year == 2
+    n = r.final_year
+    for mine, g in ((r.results_year["ens"], g_ens), (r.results_year["dlc"], g_dlc), (r.results_year["nlc"], g_nlc)):
+        se = math.sqrt(np.var(mine, ddof=1) / n + g.var(ddof=1) / g.size)
+        assert abs(np.mean(mine) - g.mean()) < 4 * se, (np.mean(mine), g.mean(), se)
+    assert r.eens == pytest.approx(np.mean(r.results_year["ens"])) and r.lole == pytest.approx(np.mean(r.results_year["dlc"]))
+    assert r.years_evaluated == r.final_year and r.total_loss_hours == int(r.results_year["dlc"].sum())
+    # weak points: the same three units lead, L11's share is driven by the emulated isolated-bus behaviour
+    g_imp = np.array(seq_golden["comp_importance"])
+    assert set(np.argsort(-r.comp_importance)[:3]) == set(np.argsort(-g_imp)[:3]) == {22, 23, 32}
+    assert r.comp_importance[43] == pytest.approx(g_imp[43], rel=0.35)
+    assert r.nodal_eens_avg.sum() == pytest.approx(r.eens, rel=0.02)
+    g_nodal = np.array(seq_golden["nodal_eens_avg"])
+    assert set(np.argsort(-r.nodal_eens_avg)[:5]) & set(np.argsort(-g_nodal)[:5])
+    r.write_nodal_csv(str(tmp_path / "seq_nodal_results.csv")); r.save_mat(str(tmp_path / "seq_reliability_results.mat"))
+    csv = np.loadtxt(str(tmp_path / "seq_nodal_results.csv"), delimiter=",", skiprows=1)
+    np.testing.assert_allclose(csv[:, 1], r.nodal_eens_avg, rtol=1e-12)
+
+
+@pytest.mark.gpu
+def test_gpu_long_run_tightens_on_golden(seqeng, seq_golden):
+    """20 000 simulated years (about 1.4e8 hourly OPFs): the golden means sit within the golden run's own error."""
+    ens, dlc, nlc = [], [], []
+    for b in range(20):
+        e, d, n_, _, acc = seqeng.seq_years(77, b * 1000, 1000)
+        ens.append(e); dlc.append(d); nlc.append(n_)
+        assert acc.n_nonconverged == 0
+    for mine, key in ((np.concatenate(ens), "ens"), (np.concatenate(dlc), "dlc"), (np.concatenate(nlc), "nlc")):
+        g = np.array(seq_golden[key], dtype=float)
+        se = math.sqrt(mine.var(ddof=1) / mine.size + g.var(ddof=1) / g.size)
+        assert abs(mine.mean() - g.mean()) < 4 * se, (key, mine.mean(), g.mean(), se)
