@@ -87,3 +87,69 @@ def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, be
         beta = idx["beta"]
         hist.append((done, beta, idx["edns"], idx["lole"], idx["plc"]))
     return idx, total, hist
+
+
+def allgather_years(arr: np.ndarray, counts, device=None) -> np.ndarray:
+    """Concatenate per-rank [n_r, 3] annual (ens, dlc, nlc) arrays in rank order (ranks may own n or n+1 years)."""
+    import torch
+    import torch.distributed as dist
+    if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
+        return arr
+    m = max(counts)
+    pad = np.zeros((m, 3)); pad[:arr.shape[0]] = arr
+    t = torch.from_numpy(pad)
+    if dist.get_backend() == "nccl":
+        t = t.to(device if device is not None else torch.device("cuda", torch.cuda.current_device()))
+    out = [torch.empty_like(t) for _ in range(dist.get_world_size())]
+    dist.all_gather(out, t)
+    return np.concatenate([o.cpu().numpy()[:c] for o, c in zip(out, counts)], axis=0)
+
+
+def seq_run_distributed(years_fn, *, seed: int = 1, cov_threshold: float = 0.05, max_sim_years: int = 4000,
+                        batch_years: int = 64, rank: int | None = None, world: int | None = None, device=None):
+    """The seqMain loop (seqMain.m:85-199) over `world` ranks: every super-batch of simulated years
+    [done, done + batch_years) is split contiguously across the ranks (years are independent streams keyed by
+    (seed, global year)), the annual (ens, dlc, nlc) triples are all-gathered in year order so that every rank
+    walks the same CoV curve and stops at the same year, and the post-processing accumulators are all-reduced.
+
+    years_fn(seed, first_year, n_years) -> (ens[n], dlc[n], nlc[n], Acc) evaluates years on THIS rank
+    (SeqEngine.seq_years in production).  Returns dict(final_year, eens, cov, lole, lolf, years[n,3], cum_eens,
+    cum_cov, acc) — acc covers exactly the years up to the stopping year, as seqMain.m:146-159.
+    """
+    import torch.distributed as dist
+    if rank is None or world is None:
+        if dist.is_available() and dist.is_initialized():
+            rank, world = dist.get_rank(), dist.get_world_size()
+        else:
+            rank, world = 0, 1
+    total = _abi.Acc()
+    years = np.zeros((0, 3)); cum_eens, cum_cov = [], []
+    done, stop = 0, False
+    while done < max_sim_years and not stop:
+        m = min(batch_years, max_sim_years - done)
+        shards = [shard_range(done, m, r, world) for r in range(world)]
+        lo, cnt = shards[rank]
+        if cnt > 0:
+            e, d, n_, acc = years_fn(seed, lo, cnt)
+            mine = np.column_stack([e, d, n_])
+        else:
+            mine, acc = np.zeros((0, 3)), _abi.Acc()
+        batch = allgather_years(mine, [c for _, c in shards], device)
+        used = m
+        for k in range(m):
+            years = np.vstack([years, batch[k:k + 1]])
+            y = years.shape[0]
+            mean = float(years[:, 0].mean())
+            cov = float(years[:, 0].std(ddof=1) / (mean * np.sqrt(y))) if y > 1 and mean > 0 else 0.0
+            cum_eens.append(mean); cum_cov.append(cov)
+            if y > 1 and 0 < cov < cov_threshold:
+                stop, used = True, k + 1
+                break
+        if used < m:        # stopping year inside this batch: accumulate exactly the years up to it
+            hi = done + used
+            cnt2 = max(0, min(lo + cnt, hi) - lo)
+            acc = years_fn(seed, lo, cnt2)[3] if cnt2 > 0 else _abi.Acc()
+        total = merge(total, allreduce_acc(acc, device))
+        done += used
+    return dict(final_year=years.shape[0], eens=cum_eens[-1], cov=cum_cov[-1], lole=float(years[:, 1].mean()),
+                lolf=float(years[:, 2].mean()), years=years, cum_eens=np.array(cum_eens), cum_cov=np.array(cum_cov), acc=total)

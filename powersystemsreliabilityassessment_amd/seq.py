@@ -111,6 +111,18 @@ class SeqEngine:
         a = np.array([(y.ens, y.dlc, y.nlc, y.n_contingency) for y in yrs], dtype=np.float64).reshape(-1, 4)
         return a[:, 0], a[:, 1], a[:, 2], a[:, 3].astype(np.int64), acc
 
+    def seqMain_distributed(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD, *, seed: int = 1,
+                            mpopt=None, batch_years: int = 512, device=None) -> dict:
+        """seqMain over the ranks of the default torch.distributed group (one process per GPU): years shard
+        contiguously per super-batch, see dist.seq_run_distributed."""
+        from . import dist as rdist
+
+        def fn(sd, first, n):
+            e, d, n_, _, acc = self.seq_years(sd, first, n, mpopt)
+            return e, d, n_, acc
+        return rdist.seq_run_distributed(fn, seed=seed, cov_threshold=cov_threshold, max_sim_years=max_sim_years,
+                                         batch_years=batch_years, device=device)
+
     # seqMain.m:85-262
     def seqMain(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD,
                 curtail_threshold: float = CURTAIL_THRESHOLD, *, seed: int = 1, mpopt=None, batch_years: int = 64) -> "SeqResult":
