@@ -26,10 +26,13 @@ struct relmc_ctx {
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool has_case = false;
-    DevCase hcase;
-    DevCase* dcase = nullptr;
-    Partial* dpartial = nullptr;
-    int partial_blocks = 0;
+    int tile = 0;                        // 0: Tile24 (16-lane rows), 1: Tile96 (one scenario per wavefront)
+    DevCaseT<Tile24> hcase24;
+    DevCaseT<Tile96> hcase96;
+    void* dcase = nullptr;               // device image of the active tile's case
+    int nb = 0, ng = 0, nl = 0, ncomp = 0;
+    void* dpartial = nullptr;
+    size_t partial_bytes = 0;
     DevAcc* dacc = nullptr;
     int num_cu = 0;
     int blocks_per_cu = 0;
@@ -71,45 +74,69 @@ EvalArgs make_args(const relmc_solver_opts& o)
     return a;
 }
 
+template <class TL>
 int grid_for(relmc_ctx* ctx, int64_t n)
 {
-    const int64_t groups = ((n + 3) / 4 + WPB - 1) / WPB;
+    const int64_t groups = ((n + TL::SPW - 1) / TL::SPW + TL::WPB - 1) / TL::WPB;
     int64_t g = (int64_t)ctx->num_cu * ctx->blocks_per_cu;
     if (g > groups) g = groups;
     if (g < 1) g = 1;
     return (int)g;
 }
 
-int ensure_partial(relmc_ctx* ctx, int blocks)
+int ensure_partial(relmc_ctx* ctx, size_t bytes)
 {
-    if (blocks <= ctx->partial_blocks) return RELMC_OK;
+    if (bytes <= ctx->partial_bytes) return RELMC_OK;
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
-    ctx->dpartial = nullptr; ctx->partial_blocks = 0;
-    HIP_TRY(ctx, hipMalloc(&ctx->dpartial, sizeof(Partial) * 64 * WPB * (size_t)blocks));
-    ctx->partial_blocks = blocks;
+    ctx->dpartial = nullptr; ctx->partial_bytes = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->dpartial, bytes));
+    ctx->partial_bytes = bytes;
     return RELMC_OK;
 }
 
-template <int MODE>
-int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* blocks_out)
+// launches the evaluation kernel of the active tile; *rows_out = scenario rows holding partial accumulators
+template <int MODE, class TL>
+int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
 {
-    const int blocks = grid_for(ctx, a.n);
-    int rc = ensure_partial(ctx, blocks);
+    const int blocks = grid_for<TL>(ctx, a.n);
+    int rc = ensure_partial(ctx, sizeof(PartialT<TL>) * 64 * TL::WPB * (size_t)blocks);
     if (rc) return rc;
     a.partial = ctx->dpartial;
     a.scen_doubles = ctx->scen_doubles;
     a.stash_off = ctx->stash_off;
-#ifdef RELMC_PHASE_TIMING
+#if defined(RELMC_PHASE_TIMING) || defined(RELMC_TRACE)
     if (!ctx->dtiming) HIP_TRY(ctx, hipMalloc(&ctx->dtiming, sizeof(unsigned long long) * 8 * 65536));
-    a.timing = ctx->dtiming; ctx->timing_waves = blocks * WPB;
+    a.timing = ctx->dtiming; ctx->timing_waves = blocks * TL::WPB;
 #else
     a.timing = nullptr;
 #endif
     HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL((relmc_eval_kernel<MODE>), dim3(blocks), dim3(64 * WPB), ctx->lds_bytes, ctx->stream, ctx->dcase, a);
+    hipLaunchKernelGGL((relmc_eval_kernel<MODE, TL>), dim3(blocks), dim3(64 * TL::WPB), ctx->lds_bytes, ctx->stream,
+                       reinterpret_cast<const DevCaseT<TL>*>(ctx->dcase), a);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
-    *blocks_out = blocks;
+    *rows_out = blocks * TL::WPB * TL::SPW;
+    return RELMC_OK;
+}
+
+template <int MODE>
+int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
+{
+    if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out);
+    if constexpr (MODE == 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "the sequential track is built for the 16-lane tile (<= 128 components)");
+    else return launch_eval_t<MODE, Tile96>(ctx, a, rows_out);
+}
+
+// deterministic reduction of the partial records into the device image of relmc_acc
+int launch_finalize(relmc_ctx* ctx, int rows)
+{
+    if (ctx->tile == 0)
+        hipLaunchKernelGGL(relmc_finalize_kernel<Tile24>, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase),
+                           reinterpret_cast<const PartialT<Tile24>*>(ctx->dpartial), rows, ctx->dacc);
+    else
+        hipLaunchKernelGGL(relmc_finalize_kernel<Tile96>, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase),
+                           reinterpret_cast<const PartialT<Tile96>*>(ctx->dpartial), rows, ctx->dacc);
+    HIP_TRY(ctx, hipGetLastError());
     return RELMC_OK;
 }
 
@@ -122,99 +149,22 @@ int finish_timing(relmc_ctx* ctx)
     return RELMC_OK;
 }
 
-}  // namespace
-
-extern "C" {
-
-const char* relmc_version(void) { return "relmc 0.2 (gfx950; 16-lane DPP-row IPM, sparse 2x2-block LDL' in LDS, static schedule)"; }
-
-const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
-
-int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
-{
-    if (!out) return RELMC_ERR_INVALID;
-    *out = nullptr;
-    int ndev = 0;
-    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RELMC_ERR_NO_DEVICE;
-    if (device_id < 0 || device_id >= ndev) return RELMC_ERR_INVALID;
-    relmc_ctx* ctx = new (std::nothrow) relmc_ctx();
-    if (!ctx) return RELMC_ERR_INVALID;
-    ctx->device = device_id;
-    hipDeviceProp_t prop;
-    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
-        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
-        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc(&ctx->dcase, sizeof(DevCase)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess) {
-        delete ctx;
-        return RELMC_ERR_NO_DEVICE;
-    }
-    ctx->num_cu = prop.multiProcessorCount;
-    ctx->blocks_per_cu = 1;
-    *out = ctx;
-    return RELMC_OK;
-}
-
-void relmc_ctx_destroy(relmc_ctx* ctx)
-{
-    if (!ctx) return;
-    (void)hipSetDevice(ctx->device);
-    if (ctx->dpartial) (void)hipFree(ctx->dpartial);
-    if (ctx->dcase) (void)hipFree(ctx->dcase);
-    if (ctx->dacc) (void)hipFree(ctx->dacc);
-    if (ctx->dhl1) (void)hipFree(ctx->dhl1);
-    if (ctx->dseq) (void)hipFree(ctx->dseq);
-    if (ctx->dlf) (void)hipFree(ctx->dlf);
-    if (ctx->dsorted) (void)hipFree(ctx->dsorted);
-    if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
-    if (ctx->dtiming) (void)hipFree(ctx->dtiming);
-    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
-    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
-    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
-    delete ctx;
-}
-
-void relmc_solver_opts_default(relmc_solver_opts* o)
-{
-    if (!o) return;
-    o->singular_policy = RELMC_REFERENCE_EMULATE;
-    o->max_it = 150;
-    o->feastol = 5e-6; o->gradtol = 1e-6; o->comptol = 1e-6; o->costtol = 1e-6;
-    o->xi = 0.99995; o->sigma = 0.1; o->z0 = 1.0; o->alpha_min = 1e-8; o->max_stepsize = 1e10;
-}
-
-void relmc_nsq_opts_default(relmc_nsq_opts* o)
-{
-    if (!o) return;
-    std::memset(o, 0, sizeof(*o));
-    o->beta_limit = 0.0017;       /* nsqMain.m:60 */
-    o->max_samples = 100000;      /* nsqMain.m:61 */
-    o->batch = 100;               /* nsqMain.m:62 */
-    o->seed = 1;
-    o->hours_per_year = 8760.0;   /* nsqMain.m:292 */
-    relmc_solver_opts_default(&o->solver);
-}
-
 // Build the device tables from the plain case description: internal bus numbering = elimination
 // order of the sparse block LDL' (level-then-min-fill, reference bus last), symbolic fill, the
 // static task schedule the kernel interprets, incidence lists, thresholds.  Mirrors what
 // nsqMain.m:42-167 prepares once before its Monte Carlo loop.
-int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
+template <class TL>
+int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
 {
-    if (!ctx) return RELMC_ERR_INVALID;
-    if (!d || !d->bus_pd || !d->inj_bus || !d->inj_pmin || !d->inj_pmax || !d->inj_cost || !d->br_from ||
-        !d->br_to || !d->br_b || !d->br_rate || !d->unavail || !d->always_up)
-        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: null field in case description");
+    constexpr int NBT = TL::NBT, NLT = TL::NLT, NIT = TL::NIT, NCOMPMAX = TL::NCOMPMAX, MAXOFF = TL::MAXOFF, MAXPASS = TL::MAXPASS,
+                  ROWL = TL::RW, IS = TL::IS, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     const int nb = d->nb, ng = d->ng, nl = d->nl, nd = d->nd, ninj = ng + nd, ncomp = ng + nl;
-    if (nb < 1 || ng < 0 || nl < 0 || nd < 0 || d->ref_bus < 0 || d->ref_bus >= nb || !(d->base_mva > 0))
-        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
-    if (nb > NBT || nl > NLT || ninj > NIT || ncomp > NCOMPMAX)
-        return fail(ctx, RELMC_ERR_UNSUPPORTED,
-                    "relmc_case_load: case exceeds the compiled tile (32 buses, 48 lines, 64 injections)");
-    DevCase& C = ctx->hcase;
+    if (nb > NBT || nl > NLT || ninj > NIT || ncomp > NCOMPMAX || nl > 126 || ninj > 254)
+        return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case exceeds the compiled tiles (128 buses, 126 lines, 192 injections, 256 components)");
     std::memset(&C, 0, sizeof(C));
     C.nb = nb; C.ng = ng; C.nl = nl; C.nd = nd; C.ninj = ninj; C.ncomp = ncomp;
     C.base_mva = d->base_mva; C.total_load = d->total_load;
-    C.exist_mask = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);
+    C.exist_mask = nb >= 32 ? 0xffffffffu : ((1u << nb) - 1u);      // used by the 16-lane tile only (nb <= 32 there)
 
     // ---- elimination order on the bus graph (all lines in service = superset of every outage state)
     std::vector<std::vector<char>> A(nb, std::vector<char>(nb, 0));
@@ -389,12 +339,12 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         C.b_inj[bus][C.b_ninj[bus]++] = (uint8_t)j;
         if (j >= ng) {
             if (C.b_vinj[bus] >= 0) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: two virtual generators at one bus");
-            C.b_vinj[bus] = (int8_t)j;
+            C.b_vinj[bus] = (int16_t)j;
         }
     }
     for (int i = 0; i < nb; ++i) {
         uint64_t pk = 0;
-        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : 0x7f) << (8 * e);
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : 0xff) << (8 * e);
         C.b_inj8[i] = pk;
         if (C.b_ninj[i] > maxinj_) maxinj_ = C.b_ninj[i];
     }
@@ -418,29 +368,127 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     uint32_t scen = C.nws > eval_doubles ? C.nws : eval_doubles;
     scen = (scen + 1u) & ~1u;
     ctx->stash_off = scen;
-    scen += 2u * IS * ROWL + NBT;                          // stash: 1/D and Np/D per injection lane; lambda per bus
+    scen += 2u * IS * ROWL + NBT + OW / 2u;                // stash: 1/D and Np/D per injection lane; lambda per bus; outage mask words
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     ctx->scen_doubles = scen;
-    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
-    ctx->lds_bytes = ((case_bytes + 15u) & ~15u) + 4u * WPB * scen * (uint32_t)sizeof(double);
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
+    ctx->lds_bytes = ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
-    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
+    if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, TL>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
     ctx->blocks_per_cu = bpc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase, &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->nb = nb; ctx->ng = ng; ctx->nl = nl; ctx->ncomp = ncomp;
+    ctx->has_seq = false;
     ctx->has_case = true;
     return RELMC_OK;
+}
+
+
+}  // namespace
+
+extern "C" {
+
+const char* relmc_version(void) { return "relmc 0.2 (gfx950; 16-lane DPP-row IPM, sparse 2x2-block LDL' in LDS, static schedule)"; }
+
+const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
+
+int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
+{
+    if (!out) return RELMC_ERR_INVALID;
+    *out = nullptr;
+    int ndev = 0;
+    if (hipGetDeviceCount(&ndev) != hipSuccess || ndev <= 0) return RELMC_ERR_NO_DEVICE;
+    if (device_id < 0 || device_id >= ndev) return RELMC_ERR_INVALID;
+    relmc_ctx* ctx = new (std::nothrow) relmc_ctx();
+    if (!ctx) return RELMC_ERR_INVALID;
+    ctx->device = device_id;
+    hipDeviceProp_t prop;
+    if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
+        hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
+        hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
+        hipMalloc(&ctx->dcase, sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess) {
+        delete ctx;
+        return RELMC_ERR_NO_DEVICE;
+    }
+    ctx->num_cu = prop.multiProcessorCount;
+    ctx->blocks_per_cu = 1;
+    *out = ctx;
+    return RELMC_OK;
+}
+
+void relmc_ctx_destroy(relmc_ctx* ctx)
+{
+    if (!ctx) return;
+    (void)hipSetDevice(ctx->device);
+    if (ctx->dpartial) (void)hipFree(ctx->dpartial);
+    if (ctx->dcase) (void)hipFree(ctx->dcase);
+    if (ctx->dacc) (void)hipFree(ctx->dacc);
+    if (ctx->dhl1) (void)hipFree(ctx->dhl1);
+    if (ctx->dseq) (void)hipFree(ctx->dseq);
+    if (ctx->dlf) (void)hipFree(ctx->dlf);
+    if (ctx->dsorted) (void)hipFree(ctx->dsorted);
+    if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
+    if (ctx->dtiming) (void)hipFree(ctx->dtiming);
+    if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
+    if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
+    if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
+    delete ctx;
+}
+
+void relmc_solver_opts_default(relmc_solver_opts* o)
+{
+    if (!o) return;
+    o->singular_policy = RELMC_REFERENCE_EMULATE;
+    o->max_it = 150;
+    o->feastol = 5e-6; o->gradtol = 1e-6; o->comptol = 1e-6; o->costtol = 1e-6;
+    o->xi = 0.99995; o->sigma = 0.1; o->z0 = 1.0; o->alpha_min = 1e-8; o->max_stepsize = 1e10;
+}
+
+void relmc_nsq_opts_default(relmc_nsq_opts* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->beta_limit = 0.0017;       /* nsqMain.m:60 */
+    o->max_samples = 100000;      /* nsqMain.m:61 */
+    o->batch = 100;               /* nsqMain.m:62 */
+    o->seed = 1;
+    o->hours_per_year = 8760.0;   /* nsqMain.m:292 */
+    relmc_solver_opts_default(&o->solver);
+}
+
+// Build the device tables from the plain case description: internal bus numbering = elimination
+// order of the sparse block LDL' (level-then-min-fill, reference bus last), symbolic fill, the
+// static task schedule the kernel interprets, incidence lists, thresholds.  Mirrors what
+// nsqMain.m:42-167 prepares once before its Monte Carlo loop.
+int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!d || !d->bus_pd || !d->inj_bus || !d->inj_pmin || !d->inj_pmax || !d->inj_cost || !d->br_from ||
+        !d->br_to || !d->br_b || !d->br_rate || !d->unavail || !d->always_up)
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: null field in case description");
+    const int nb = d->nb, ng = d->ng, nl = d->nl, nd = d->nd;
+    if (nb < 1 || ng < 0 || nl < 0 || nd < 0 || d->ref_bus < 0 || d->ref_bus >= nb || !(d->base_mva > 0))
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
+    ctx->has_case = false;
+    // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
+    if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
+        ctx->tile = 0;
+        return case_load_impl<Tile24>(ctx, d, ctx->hcase24);
+    }
+    ctx->tile = 1;
+    return case_load_impl<Tile96>(ctx, d, ctx->hcase96);
 }
 
 int32_t relmc_case_thresholds(const relmc_ctx* ctx, uint32_t* out)
 {
     if (!ctx || !out) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return RELMC_ERR_NO_CASE;
-    std::memcpy(out, ctx->hcase.thr, sizeof(uint32_t) * ctx->hcase.ncomp);
+    std::memcpy(out, ctx->tile == 0 ? ctx->hcase24.thr : ctx->hcase96.thr, sizeof(uint32_t) * ctx->ncomp);
     return RELMC_OK;
 }
 
@@ -451,10 +499,13 @@ int32_t relmc_mc_sampling_dev(relmc_ctx* ctx, uint64_t seed, uint64_t first_inde
     if (n < 0 || (n > 0 && !eqstatus_dev)) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_sampling: bad arguments");
     if (n == 0) return RELMC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t total = n * ((ctx->hcase.ncomp + 3) / 4);
+    const int64_t total = n * ((ctx->ncomp + 3) / 4);
     int64_t blocks = (total + 255) / 256;
     if (blocks > (int64_t)ctx->num_cu * 16) blocks = (int64_t)ctx->num_cu * 16;
-    hipLaunchKernelGGL(relmc_sampling_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->dcase, seed, first_index, n, eqstatus_dev);
+    if (ctx->tile == 0)
+        hipLaunchKernelGGL(relmc_sampling_kernel<Tile24>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index, n, eqstatus_dev);
+    else
+        hipLaunchKernelGGL(relmc_sampling_kernel<Tile96>, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index, n, eqstatus_dev);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
     return RELMC_OK;
@@ -468,7 +519,7 @@ int32_t relmc_mc_sampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, i
     if (n == 0) return RELMC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     uint8_t* dbuf = nullptr;
-    const size_t bytes = (size_t)n * ctx->hcase.ncomp;
+    const size_t bytes = (size_t)n * ctx->ncomp;
     HIP_TRY(ctx, hipMalloc(&dbuf, bytes));
     int rc = relmc_mc_sampling_dev(ctx, seed, first_index, n, dbuf);
     if (rc == RELMC_OK && hipMemcpy(eqstatus_host, dbuf, bytes, hipMemcpyDeviceToHost) != hipSuccess)
@@ -503,7 +554,7 @@ int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t 
     if (n < 0 || (n > 0 && (!states_host || !dns_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_simulation: bad arguments");
     if (n == 0) return RELMC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int ncomp = ctx->hcase.ncomp, nb = ctx->hcase.nb;
+    const int ncomp = ctx->ncomp, nb = ctx->nb;
     uint8_t* dst = nullptr; double* ddns = nullptr; double* dnod = nullptr; int32_t* dstat = nullptr; int32_t* dit = nullptr;
     int rc = RELMC_OK;
     auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
@@ -547,8 +598,8 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
         int blocks = 0;
         int rc = launch_eval<0>(ctx, a, &blocks);
         if (rc) return rc;
-        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks * 4 * WPB, ctx->dacc);
-        HIP_TRY(ctx, hipGetLastError());
+        rc = launch_finalize(ctx, blocks);
+        if (rc) return rc;
         relmc_acc part;
         HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
         rc = finish_timing(ctx);
@@ -608,11 +659,12 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_load: no case loaded");
+    if (ctx->tile != 0) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_seq_load: the sequential track is built for the 16-lane tile (<= 128 components)");
     if (!mttf || !mttr || !load_factors || hpy < 1 || hpy > 65535) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     SeqCase& q = ctx->hseq;
     std::memset(&q, 0, sizeof(q));
-    q.ncomp = ctx->hcase.ncomp; q.hpy = hpy;
+    q.ncomp = ctx->ncomp; q.hpy = hpy;
     for (int k = 0; k < q.ncomp; ++k) {
         if (!(mttf[k] > 0) || !(mttr[k] > 0)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: MTTF / MTTR must be positive");
         q.mttf[k] = mttf[k]; q.mttr[k] = mttr[k];
@@ -623,7 +675,7 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
     HIP_TRY(ctx, hipMalloc(&ctx->dlf, sizeof(double) * hpy));
     HIP_TRY(ctx, hipMemcpy(ctx->dseq, &q, sizeof(q), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dlf, load_factors, sizeof(double) * hpy, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2, Tile24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     ctx->has_seq = true;
     return RELMC_OK;
 }
@@ -675,7 +727,7 @@ int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     relmc_solver_opts o;
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
-    const int ncomp = ctx->hcase.ncomp, nb = ctx->hcase.nb;
+    const int ncomp = ctx->ncomp, nb = ctx->nb;
     uint8_t* dst = nullptr; double *dsc = nullptr, *ddns = nullptr, *dnod = nullptr; int32_t *dstat = nullptr, *dit = nullptr;
     auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(dsc); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
     if (hipMalloc(&dst, (size_t)n * ncomp) != hipSuccess || hipMalloc(&dsc, sizeof(double) * n) != hipSuccess || hipMalloc(&ddns, sizeof(double) * n) != hipSuccess ||
@@ -742,8 +794,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         int blocks = 0;
         rc = launch_eval<2>(ctx, a, &blocks);
         if (rc) { cleanup(); return rc; }
-        hipLaunchKernelGGL(relmc_finalize_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->dcase, ctx->dpartial, blocks * 4 * WPB, ctx->dacc);
-        if (hipGetLastError() != hipSuccess || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
+        if (launch_finalize(ctx, blocks) != RELMC_OK || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
         rc = finish_timing(ctx);
         if (rc) { cleanup(); return rc; }
         ms = ctx->last_kernel_ms;
@@ -830,7 +881,7 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     if (!o || !res || o->batch <= 0 || o->max_samples <= 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_run: bad options");
     std::memset(res, 0, sizeof(*res));
     const auto t0 = std::chrono::steady_clock::now();
-    const int nb = ctx->hcase.nb, ncomp = ctx->hcase.ncomp;
+    const int nb = ctx->nb, ncomp = ctx->ncomp;
     double beta = INFINITY, kernel_ms = 0.0;
     int64_t done = 0, cp = 0;
     while (beta > o->beta_limit && done < o->max_samples) {
@@ -863,11 +914,13 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
 int32_t relmc_debug_schedule(const relmc_ctx* ctx, int32_t* out9)
 {
     if (!ctx || !out9 || !ctx->has_case) return RELMC_ERR_INVALID;
-    const DevCase& C = ctx->hcase;
-    int ntask = 0;
-    for (int p = 0; p < C.npass; ++p) ntask += C.pass_ntask[p];
-    out9[0] = C.npass_upd; out9[1] = C.npass_inv; out9[2] = C.npass - C.npass_upd - C.npass_inv; out9[3] = C.noff;
-    out9[4] = C.nzero; out9[5] = (int)C.nws; out9[6] = (int)ctx->lds_bytes; out9[7] = ctx->blocks_per_cu; out9[8] = ntask;
+    auto fill = [&](const auto& C) {
+        int ntask = 0;
+        for (int p = 0; p < C.npass; ++p) ntask += C.pass_ntask[p];
+        out9[0] = C.npass_upd; out9[1] = C.npass_inv; out9[2] = C.npass - C.npass_upd - C.npass_inv; out9[3] = C.noff;
+        out9[4] = C.nzero; out9[5] = (int)C.nws; out9[6] = (int)ctx->lds_bytes; out9[7] = ctx->blocks_per_cu; out9[8] = ntask;
+    };
+    if (ctx->tile == 0) fill(ctx->hcase24); else fill(ctx->hcase96);
     return RELMC_OK;
 }
 
@@ -880,6 +933,17 @@ int32_t relmc_debug_phase_cycles(relmc_ctx* ctx, unsigned long long* out8)
     std::vector<unsigned long long> h((size_t)ctx->timing_waves * 8);
     HIP_TRY(ctx, hipMemcpy(h.data(), ctx->dtiming, h.size() * sizeof(unsigned long long), hipMemcpyDeviceToHost));
     for (int w = 0; w < ctx->timing_waves; ++w) for (int k = 0; k < 8; ++k) out8[k] += h[(size_t)w * 8 + k];
+    return RELMC_OK;
+}
+
+// debug hook (only meaningful in -DRELMC_TRACE builds): per-iteration termination quantities of the first scenario
+// of the last launch, 8 doubles per iteration {feascond, gradcond, compcond, costcond, alpha_p, alpha_d, gamma, f}
+int32_t relmc_debug_trace(relmc_ctx* ctx, double* out, int32_t n_doubles)
+{
+    if (!ctx || !out || n_doubles < 0) return RELMC_ERR_INVALID;
+    for (int k = 0; k < n_doubles; ++k) out[k] = 0.0;
+    if (!ctx->dtiming || n_doubles > 8 * 65536) return RELMC_OK;
+    HIP_TRY(ctx, hipMemcpy(out, ctx->dtiming, sizeof(double) * n_doubles, hipMemcpyDeviceToHost));
     return RELMC_OK;
 }
 

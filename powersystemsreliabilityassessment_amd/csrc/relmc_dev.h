@@ -6,19 +6,30 @@
 
 namespace relmc {
 
-// ---- tile geometry: one scenario = one 16-lane DPP row of a wavefront -----------------
-constexpr int ROWL = 16;           // lanes per scenario
-constexpr int BS = 2;              // bus slots per lane      (NBT = 32 buses)
-constexpr int LS = 3;              // line slots per lane     (NLT = 48 lines)
-constexpr int IS = 4;              // injection slots/lane    (NIT = 64 injections)
-constexpr int NBT = BS * ROWL;
-constexpr int NLT = LS * ROWL;
-constexpr int NIT = IS * ROWL;
+// ---- tile geometry: one scenario = one row of RW lanes of a wavefront (64 / RW scenarios per wavefront) -----
+//   Tile24: 16-lane DPP rows, 4 scenarios per wavefront  (<= 32 buses, 48 lines, 64 injections: IEEE RTS-24)
+//   Tile96: one scenario per wavefront                   (<= 128 buses, 128 lines, 192 injections: IEEE RTS-96)
+template <int RW_, int BS_, int LS_, int IS_, int NCOMPMAX_, int MAXPASS_, int MAXOFF_, int WPB_>
+struct TileT {
+    static constexpr int RW = RW_;             // lanes per scenario
+    static constexpr int BS = BS_;             // bus slots per lane
+    static constexpr int LS = LS_;             // line slots per lane
+    static constexpr int IS = IS_;             // injection slots per lane
+    static constexpr int NBT = BS_ * RW_;
+    static constexpr int NLT = LS_ * RW_;
+    static constexpr int NIT = IS_ * RW_;
+    static constexpr int SPW = 64 / RW_;       // scenarios per wavefront
+    static constexpr int NCOMPMAX = NCOMPMAX_; // sampled components (generators + lines)
+    static constexpr int OW = NCOMPMAX_ / 32;  // 32-bit words of the outage mask
+    static constexpr int MAXPASS = MAXPASS_;   // passes of the static solver schedule
+    static constexpr int MAXOFF = MAXOFF_;     // off-diagonal 2x2 blocks of the factor (lines + fill)
+    static constexpr int WPB = WPB_;           // wavefronts per workgroup (they share the case tables)
+    static_assert(BS_ <= 2 && LS_ <= 3 && IS_ <= 4, "the per-lane flag word has room for 2 bus, 3 line and 4 injection slots");
+};
+using Tile24 = TileT<16, 2, 3, 4, 128, 96, 160, 4>;
+using Tile96 = TileT<64, 2, 2, 3, 256, 64, 320, 8>;
 constexpr int DEGMAX = 8;          // lines per bus
 constexpr int BINJMAX = 8;         // injections per bus
-constexpr int NCOMPMAX = 128;      // sampled components (generators + lines)
-constexpr int MAXPASS = 96;        // passes of the static solver schedule
-constexpr int MAXOFF = 160;        // off-diagonal 2x2 blocks of the factor (lines + fill)
 
 // l_info: from | to<<8 | flags<<24   (internal bus numbers = elimination positions)
 constexpr uint32_t LF_EXISTS = 1u, LF_OWNER = 2u, LF_LIMITED = 4u;
@@ -35,16 +46,18 @@ constexpr uint32_t IK_NONE = 0u, IK_REAL = 1u, IK_VIRTUAL = 2u;
 //   [4*nb, 4*(nb+noff))       off-diagonal blocks K(a, i), a eliminated after i (lines and fill)
 //   [off_rhs, off_rhs+4*nb)   right-hand side as a pseudo-bus: block i = [[y_theta, y_lambda], [0, 0]]
 //   [off_p, off_p+4*nb)       P_i = inv(D_i) after the factorisation
-struct DevCase {
+template <class TL>
+struct DevCaseT {
+    static constexpr int NBT = TL::NBT, NLT = TL::NLT, NIT = TL::NIT, NCOMPMAX = TL::NCOMPMAX, MAXPASS = TL::MAXPASS, MAXOFF = TL::MAXOFF, ROWL = TL::RW;
     int32_t nb, ng, nl, nd, ninj, ncomp, ref_bus, noff;
     double base_mva, total_load;
-    uint32_t exist_mask;            // bit i = bus i exists
+    uint32_t exist_mask;            // bit i = bus i exists (16-lane tile only)
     uint32_t nws;                   // doubles in W
     uint16_t off_rhs, off_p;
     uint16_t npass, npass_upd, npass_inv, nzero;
     uint16_t maxdeg, maxinj, base_connected, pad2;   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
     uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), 0x7f = none
-    uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0x7f = none
+    uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0xff = none
     // lines
     double l_b[NLT];
     double l_rate[NLT];             // p.u. (0 = unlimited)
@@ -62,7 +75,7 @@ struct DevCase {
     uint8_t b_line[NBT][DEGMAX];    // line id | 0x80 when the bus is the line's 'to' end
     uint8_t b_ninj[NBT];
     uint8_t b_inj[NBT][BINJMAX];
-    int8_t b_vinj[NBT];             // virtual generator at the bus, -1 if none
+    int16_t b_vinj[NBT];            // virtual generator at the bus, -1 if none
     uint8_t b_ext[NBT];             // internal bus -> external bus number
     uint8_t b_int[NBT];             // external bus number -> internal bus
     uint32_t thr[NCOMPMAX];         // Bernoulli thresholds floor(U*2^32)
@@ -73,12 +86,13 @@ struct DevCase {
 };
 
 // per-lane partial accumulators written once per workgroup-row, reduced by relmc_finalize_kernel
-struct Partial {
+template <class TL>
+struct PartialT {
     double dns, dns2;
-    double shed[IS];
+    double shed[TL::IS];
     uint32_t n, nfail, nsing, ninf, nnc, iters;
-    uint32_t cf_inj[IS];
-    uint32_t cf_line[LS];
+    uint32_t cf_inj[TL::IS];
+    uint32_t cf_line[TL::LS];
     uint32_t pad;
 };
 
@@ -94,7 +108,7 @@ struct EvalArgs {
     double* nodal;
     int32_t* status;
     int32_t* iters;
-    Partial* partial;               // [gridDim.x * blockDim.x]
+    void* partial;                  // PartialT<tile>[gridDim.x * blockDim.x]
     uint32_t scen_doubles;          // per-scenario LDS doubles (workspace + stash), = 2 mod 4
     uint32_t stash_off;             // start of the per-lane stash behind the workspace
     unsigned long long* timing;     // profiling builds: [waves][8] phase cycle counters (else null)

@@ -24,10 +24,6 @@ namespace relmc {
 
 #define DEVFI __device__ __forceinline__
 
-#ifndef RELMC_WPB
-#define RELMC_WPB 4                 // wavefronts per workgroup (they share the case tables; never synchronise after the prologue)
-#endif
-constexpr int WPB = RELMC_WPB;
 #ifndef RELMC_MIN_WAVES
 #define RELMC_MIN_WAVES 2          // waves per SIMD the register allocator must allow (<= 256 VGPRs)
 #endif
@@ -37,12 +33,59 @@ DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf
 template <int CTRL>
 DEVFI uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true); }
 
-// all-reduce over the 16 lanes of a row (row_ror 8,4,2,1); every lane gets bit-identical results
-DEVFI double row_sum(double v) { v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v); return v; }
-DEVFI double row_max(double v) { v = __builtin_fmax(v, dppd<0x128>(v)); v = __builtin_fmax(v, dppd<0x124>(v)); v = __builtin_fmax(v, dppd<0x122>(v)); v = __builtin_fmax(v, dppd<0x121>(v)); return v; }
-DEVFI double row_min(double v) { v = __builtin_fmin(v, dppd<0x128>(v)); v = __builtin_fmin(v, dppd<0x124>(v)); v = __builtin_fmin(v, dppd<0x122>(v)); v = __builtin_fmin(v, dppd<0x121>(v)); return v; }
-DEVFI uint32_t row_or(uint32_t v) { v |= dppu<0x128>(v); v |= dppu<0x124>(v); v |= dppu<0x122>(v); v |= dppu<0x121>(v); return v; }
-DEVFI uint32_t row_add(uint32_t v) { v += dppu<0x128>(v); v += dppu<0x124>(v); v += dppu<0x122>(v); v += dppu<0x121>(v); return v; }
+// all-reduce over the 16 lanes of a DPP row (row_ror 8,4,2,1); every lane gets bit-identical results
+DEVFI double row16_sum(double v) { v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v); return v; }
+DEVFI double row16_max(double v) { v = __builtin_fmax(v, dppd<0x128>(v)); v = __builtin_fmax(v, dppd<0x124>(v)); v = __builtin_fmax(v, dppd<0x122>(v)); v = __builtin_fmax(v, dppd<0x121>(v)); return v; }
+DEVFI double row16_min(double v) { v = __builtin_fmin(v, dppd<0x128>(v)); v = __builtin_fmin(v, dppd<0x124>(v)); v = __builtin_fmin(v, dppd<0x122>(v)); v = __builtin_fmin(v, dppd<0x121>(v)); return v; }
+DEVFI uint32_t row16_or(uint32_t v) { v |= dppu<0x128>(v); v |= dppu<0x124>(v); v |= dppu<0x122>(v); v |= dppu<0x121>(v); return v; }
+DEVFI uint32_t row16_add(uint32_t v) { v += dppu<0x128>(v); v += dppu<0x124>(v); v += dppu<0x122>(v); v += dppu<0x121>(v); return v; }
+
+// lane `l` of a wavefront as a wave-uniform (scalar) value; every lane of the wavefront must be active
+DEVFI double rdlane(double v, int l)
+{
+    union { double d; int i[2]; } u; u.d = v;
+    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l); u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
+    return u.d;
+}
+// Scenario-row all-reduces.  RW = 16: the DPP row.  RW = 64: the DPP rows first, then the four row results are
+// combined in a fixed order from scalar registers (v_readlane), so the result is wave-uniform by construction.
+template <int RW> DEVFI double row_sum(double v)
+{
+    v = row16_sum(v);
+    if constexpr (RW == 64) v = (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
+    return v;
+}
+template <int RW> DEVFI double row_max(double v)
+{
+    v = row16_max(v);
+    if constexpr (RW == 64) v = __builtin_fmax(__builtin_fmax(rdlane(v, 0), rdlane(v, 16)), __builtin_fmax(rdlane(v, 32), rdlane(v, 48)));
+    return v;
+}
+template <int RW> DEVFI double row_min(double v)
+{
+    v = row16_min(v);
+    if constexpr (RW == 64) v = __builtin_fmin(__builtin_fmin(rdlane(v, 0), rdlane(v, 16)), __builtin_fmin(rdlane(v, 32), rdlane(v, 48)));
+    return v;
+}
+template <int RW> DEVFI uint32_t row_or(uint32_t v)
+{
+    v = row16_or(v);
+    if constexpr (RW == 64) v = (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) | __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
+    return v;
+}
+template <int RW> DEVFI uint32_t row_add(uint32_t v)
+{
+    v = row16_add(v);
+    if constexpr (RW == 64) v = (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
+    return v;
+}
+// does any lane of this scenario row hold `p`?
+template <int RW> DEVFI bool row_any(bool p, int lane)
+{
+    const uint64_t b = __ballot(p);
+    if constexpr (RW == 64) return b != 0;
+    else return ((b >> (lane & 48)) & 0xffffull) != 0;
+}
 
 // 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (no IEEE division sequence)
 DEVFI double frcp(double x)
@@ -77,11 +120,8 @@ DEVFI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uin
     out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
 }
 
-DEVFI bool outbit(uint32_t o0, uint32_t o1, uint32_t o2, uint32_t o3, int k)
-{
-    const uint32_t w = k < 64 ? (k < 32 ? o0 : o1) : (k < 96 ? o2 : o3);
-    return (w >> (k & 31)) & 1u;
-}
+// outage mask of the scenario (bit k = component k failed), kept in LDS behind the workspace
+DEVFI bool outbit(const uint32_t* ob, int k) { return (ob[k >> 5] >> (k & 31)) & 1u; }
 
 struct __attribute__((aligned(16))) d2 { double x, y; };
 DEVFI d2 ld2(const double* p) { return *reinterpret_cast<const d2*>(p); }
@@ -108,12 +148,15 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 // MODE 1: explicit states (+ optional per-scenario load scale), per-scenario results written out
 // MODE 2: sequential path: scenarios = compacted (year, hour) worklist, states from the chronology bit masks,
 //         load scale from the hourly curve, curtailment written to curt[year][hour]
-template <int MODE>
-__global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCase* __restrict__ gcase, const EvalArgs a)
+template <int MODE, class TL>
+__global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
+    constexpr int RW = TL::RW, BS = TL::BS, LS = TL::LS, IS = TL::IS, NBT = TL::NBT, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
+    using DevCase = DevCaseT<TL>;
+    using Partial = PartialT<TL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
     DevCase& C = *reinterpret_cast<DevCase*>(smem);
-    const int tid = threadIdx.x, lane = tid & 63, rlane = lane & 15, row = tid >> 4;
+    const int tid = threadIdx.x, lane = tid & 63, rlane = lane & (RW - 1), row = tid / RW;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)gcase->npass + 1u) * (uint32_t)sizeof(C.task[0]);   // +1: descriptor prefetch
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(gcase);
@@ -131,8 +174,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     double* const LR = W;
     double* const IR = W + 4 * (nlp + 1);
     const int maxdeg = C.maxdeg, maxinj = C.maxinj;
-    double* const Stash = W + a.stash_off + rlane;          // [2*IS][16]: 1/D and Np/D of this lane's injections
-    double* const Lam = W + a.stash_off + 2 * IS * ROWL;     // [NBT]: bus multipliers lambda_i (kept across the solve)
+    double* const Stash = W + a.stash_off + rlane;          // [2*IS][RW]: 1/D and Np/D of this lane's injections
+    double* const Lam = W + a.stash_off + 2 * IS * RW;       // [NBT]: bus multipliers lambda_i (kept across the solve)
+    uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
     const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero;
@@ -142,17 +186,17 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     // ---- static per-lane tables -------------------------------------------------------
     uint32_t linfo[LS]; int lpart[LS];
 #pragma unroll
-    for (int s = 0; s < LS; ++s) { const int l = 16 * s + rlane; linfo[s] = C.l_info[l]; lpart[s] = C.l_partner[l]; }
-#define lb(s) C.l_b[16 * (s) + rlane]
-#define lr(s) C.l_rate[16 * (s) + rlane]
+    for (int s = 0; s < LS; ++s) { const int l = RW * s + rlane; linfo[s] = C.l_info[l]; lpart[s] = C.l_partner[l]; }
+#define lb(s) C.l_b[RW * (s) + rlane]
+#define lr(s) C.l_rate[RW * (s) + rlane]
     uint32_t iinfo[IS];
 #pragma unroll
-    for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[16 * s + rlane];
+    for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[RW * s + rlane];
 
     // ---- accumulators (nsqMain.m:282-301 in per-sample form) ---------------------------
     // They live in this lane's Partial record in HBM (L2-resident, 104 B per lane) and are updated by a
     // read-modify-write once per scenario: ~25 VGPRs cheaper than carrying them through the solver.
-    Partial& PA = a.partial[(size_t)blockIdx.x * (64 * WPB) + tid];
+    Partial& PA = reinterpret_cast<Partial*>(a.partial)[(size_t)blockIdx.x * (64 * WPB) + tid];
     {
         PA.dns = 0.0; PA.dns2 = 0.0;
 #pragma unroll
@@ -163,35 +207,42 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
     }
 
     PT_DECL
-    const int64_t ngroups = (a.n + 3) >> 2;
+    const int64_t ngroups = (a.n + SPW - 1) / SPW;
     const int64_t gwave = (int64_t)blockIdx.x * WPB + (tid >> 6);
     const int64_t gstride = (int64_t)gridDim.x * WPB;
     for (int64_t grp = gwave; grp < ngroups; grp += gstride) {
-        const int64_t sidx = grp * 4 + (lane >> 4);
+        const int64_t sidx = grp * SPW + lane / RW;
         const bool live = sidx < a.n;
         double lscale = 1.0;                 // load_scale_factor of seq_mcsimulation.m:38-42 (1 in the non-sequential path)
         int seq_year = 0, seq_hour = 0;
         RELOAD_FENCE();
 
         // per-scenario state ------------------------------------------------------------
-        // per-lane status bits (one VGPR instead of 14 lane masks in SGPRs): line in service / has a flow limit,
-        // injection in service / boxed (has inequality rows)
+        // per-lane status bits (one VGPR instead of lane masks in SGPRs):
+        //   0-2 line slot in service, 3-5 line slot has a flow limit, 6-9 injection slot in service, 10-13 injection
+        //   slot boxed (has inequality rows), 14-15 bus slot is an island's angle reference (identity theta row),
+        //   16-17 bus slot's balance row dropped, 18-20 line slot touches a pinned bus, 21-23 / 24-26 the pair block's
+        //   B entries K[th_hi][lam_lo] / K[lam_hi][th_lo] are removed (pinned column or dropped row)
         uint32_t sf = 0;
 #define L_ON(s) (((sf >> (s)) & 1u) != 0)
 #define L_ACT(s) (((sf >> (3 + (s))) & 1u) != 0)
 #define I_ON(s) (((sf >> (6 + (s))) & 1u) != 0)
 #define I_BOX(s) (((sf >> (10 + (s))) & 1u) != 0)
+#define B_PIN(t) (((sf >> (14 + (t))) & 1u) != 0)
+#define B_DROP(t) (((sf >> (16 + (t))) & 1u) != 0)
+#define L_PIN(s) (((sf >> (18 + (s))) & 1u) != 0)
+#define L_C1Z(s) (((sf >> (21 + (s))) & 1u) != 0)
+#define L_C2Z(s) (((sf >> (24 + (s))) & 1u) != 0)
         double LFv[LS], LGv[LS], lzp[LS], lzm[LS], lmup[LS], lmum[LS], cBv[LS];
         double ip[IS], izp[IS], izm[IS], imup[IS], imum[IS];
         double bth[BS], bla[BS], cBd[BS];
-        uint32_t o0 = 0, o1 = 0, o2 = 0, o3 = 0, pinned = 0, dropped = 0;
         double gamma = 1.0, fval = 0.0, f0 = 0.0, alphap = 1.0, alphad = 1.0, zmu = 0.0;
         uint32_t niq = 0;
         int it = 0, status = 0;
         bool infeas = false, singular = false, iterating = false;
         uint32_t lozero = 0;                 // bit s: lower bound of injection slot s relaxed to 0 (island rules 3, 4)
-#define ISC(s) ((16 * (s) + rlane >= ng) ? lscale : 1.0)      /* virtual generators (loads) scale with the hourly factor */
-#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[16 * (s) + rlane] * ISC(s))
+#define ISC(s) ((RW * (s) + rlane >= ng) ? lscale : 1.0)      /* virtual generators (loads) scale with the hourly factor */
+#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[RW * (s) + rlane] * ISC(s))
 #pragma unroll
         for (int s = 0; s < LS; ++s) { LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
 #pragma unroll
@@ -200,153 +251,265 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
         for (int t = 0; t < BS; ++t) { bth[t] = 0; bla[t] = 0; cBd[t] = 0; }
 
         if (live) {
-            // ===== mc_sampling.m:24-41: Bernoulli outage state (1 = failed) ==================
-            if (MODE == 0) {
-                const uint64_t gi = a.first_index + (uint64_t)sidx;
-#pragma unroll
-                for (int h = 0; h < 2; ++h) {
-                    const int blk = rlane + 16 * h;
-                    uint32_t nib = 0;
-                    if (blk * 4 < ncomp) {
-                        uint32_t w[4];
-                        philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
-#pragma unroll
-                        for (int e = 0; e < 4; ++e) {
-                            const int k = blk * 4 + e;
-                            if (k < ncomp && w[e] < C.thr[k]) nib |= 1u << e;   // strict '<', mc_sampling.m:35
-                        }
-                    }
-                    const uint32_t sh = nib << ((rlane & 7) * 4);
-                    if (h == 0) { if (rlane < 8) o0 |= sh; else o1 |= sh; }
-                    else { if (rlane < 8) o2 |= sh; else o3 |= sh; }
-                }
-            } else if (MODE == 2) {
+            // ===== mc_sampling.m:24-41: Bernoulli outage state (1 = failed) -> OB (LDS words of this row) =====
+            // LDS operations of one wavefront execute in order, so the row's lanes see each other's words after a
+            // compiler-level fence; no barrier is needed (rows never share workspace).
+            if (MODE == 2) {
                 // (year, hour) of worklist entry sidx: binary search in the per-year offsets, seqMain.m:97-100
                 int lo_ = 0, hi_ = a.seq_nyears;
                 while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int64_t)a.seq_offsets[mid] <= sidx) lo_ = mid; else hi_ = mid; }
                 seq_year = lo_;
                 seq_hour = a.seq_hours[(size_t)seq_year * a.seq_hpy + (size_t)(sidx - a.seq_offsets[seq_year])];
                 const uint32_t* m = a.seq_masks + ((size_t)seq_year * a.seq_hpy + seq_hour) * 4;
-                o0 = m[0]; o1 = m[1]; o2 = m[2]; o3 = m[3];
+                if (rlane < OW) OB[rlane] = rlane < 4 ? m[rlane] : 0u;
                 lscale = a.load_factors[seq_hour];            // seqMain.m:114
             } else {
-                if (a.load_scale) lscale = a.load_scale[sidx];
-                const uint8_t* st = a.states + sidx * ncomp;
+                if (rlane < OW) OB[rlane] = 0u;
+                RELOAD_FENCE();
+                if (MODE == 0) {
+                    const uint64_t gi = a.first_index + (uint64_t)sidx;
 #pragma unroll
-                for (int q = 0; q < NCOMPMAX / 16; ++q) {
-                    const int k = rlane + 16 * q;
-                    if (k < ncomp && st[k]) {
-                        const uint32_t bit = 1u << (k & 31);
-                        if (q < 2) o0 |= bit; else if (q < 4) o1 |= bit; else if (q < 6) o2 |= bit; else o3 |= bit;
+                    for (int h = 0; h < (TL::NCOMPMAX / 4 + RW - 1) / RW; ++h) {
+                        const int blk = rlane + RW * h;
+                        if (blk * 4 < ncomp) {
+                            uint32_t w[4], nib = 0;
+                            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
+#pragma unroll
+                            for (int e = 0; e < 4; ++e) {
+                                const int k = blk * 4 + e;
+                                if (k < ncomp && w[e] < C.thr[k]) nib |= 1u << e;   // strict '<', mc_sampling.m:35
+                            }
+                            if (nib) atomicOr(&OB[blk >> 3], nib << ((blk & 7) * 4));
+                        }
+                    }
+                } else {
+                    if (a.load_scale) lscale = a.load_scale[sidx];
+                    const uint8_t* st = a.states + sidx * ncomp;
+#pragma unroll
+                    for (int q = 0; q < TL::NCOMPMAX / RW; ++q) {
+                        const int k = rlane + RW * q;
+                        if (k < ncomp && st[k]) atomicOr(&OB[k >> 5], 1u << (k & 31));
                     }
                 }
             }
-            if (MODE != 2) { o0 = row_or(o0); o1 = row_or(o1); o2 = row_or(o2); o3 = row_or(o3); }
+            RELOAD_FENCE();
 
             // ===== mc_simulation.m:32-37: component status -> model ==========================
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
-                const int l = 16 * s + rlane;
+                const int l = RW * s + rlane;
                 const uint32_t fl = linfo[s] >> 24;
-                const bool on = (fl & LF_EXISTS) && !outbit(o0, o1, o2, o3, ng + l);
+                const bool on = (fl & LF_EXISTS) && !outbit(OB, ng + l);
                 if (on) sf |= 1u << s;
                 if (on && (fl & LF_LIMITED)) sf |= 1u << (3 + s);
             }
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
-                const int j = 16 * s + rlane;
+                const int j = RW * s + rlane;
                 const uint32_t kind = (iinfo[s] >> 8) & 0xff;
-                if (kind == IK_VIRTUAL || (kind == IK_REAL && !outbit(o0, o1, o2, o3, j))) sf |= 1u << (6 + s);
+                if (kind == IK_VIRTUAL || (kind == IK_REAL && !outbit(OB, j))) sf |= 1u << (6 + s);
             }
-
-            // ===== topology: adjacency, isolated buses, islands ===============================
-            uint32_t adjm[BS];
-            bool iso = false;
-#pragma unroll
-            for (int t = 0; t < BS; ++t) {
-                const int i = 16 * t + rlane;
-                uint32_t adj = 0;
-                if (i < nb) {
-                    const int nlb = C.b_nline[i];
-                    for (int e = 0; e < nlb; ++e) {
-                        const uint32_t ent = C.b_line[i][e];
-                        const int l = ent & 0x7f;
-                        if (!outbit(o0, o1, o2, o3, ng + l)) {
-                            const uint32_t inf = C.l_info[l];
-                            adj |= 1u << ((ent & 0x80) ? (inf & 0xff) : ((inf >> 8) & 0xff));
-                        }
-                    }
-                    iso = iso || adj == 0;
-                }
-                adjm[t] = adj;
-            }
-            const uint64_t isob = __ballot(iso);
-            const bool iso_any = ((isob >> (lane & 48)) & 0xffffull) != 0;
-            // a bus without any in-service branch makes MATPOWER's KKT matrix exactly singular; the
-            // reference consumes the start point (mc_simulation.m:41,54)
-            singular = (a.policy == 0) && iso_any;
-
-            // lines out in this scenario?  If not (95 % of the scenarios) the network is one island and the
+            // lines out in this scenario?  If not (95 % of the RTS-24 scenarios) the network is one island and the
             // reachability sweeps are skipped; the island rules still run on it.
             bool lout = false;
 #pragma unroll
             for (int s = 0; s < LS; ++s) lout = lout || (((linfo[s] >> 24) & LF_EXISTS) && !L_ON(s));
-            const bool any_lout = C.base_connected == 0 || ((__ballot(lout) >> (lane & 48)) & 0xffffull) != 0;
-            if (!singular) {
-                uint32_t remaining = C.exist_mask;
-                for (int guard = 0; guard < NBT; ++guard) {
-                    const bool more = remaining != 0;
-                    if (!__any(more)) break;
-                    if (more) {
-                        uint32_t R = any_lout ? 1u << (__ffs((int)remaining) - 1) : remaining;
-                        for (int sweep = 0; sweep < NBT; ++sweep) {
-                            if (!__any(any_lout)) break;
-                            uint32_t c = 0;
+            const bool any_lout = C.base_connected == 0 || row_any<RW>(lout, lane);
+
+            // ===== topology: isolated buses, islands, island rules (DESIGN.md "island policy") ==========
+            if constexpr (RW == 16) {
+                // 16-lane tile: bus sets are 32-bit masks in registers
+                uint32_t pinned = 0, dropped = 0;
+                uint32_t adjm[BS];
+                bool iso = false;
 #pragma unroll
-                            for (int t = 0; t < BS; ++t) if ((R >> (16 * t + rlane)) & 1u) c |= adjm[t];
-                            const uint32_t Rn = R | row_or(c);
-                            const bool ch = Rn != R;
-                            R = Rn;
-                            if (!__any(ch)) break;
-                        }
-                        // rule 1: the island's angle reference is its bus that is eliminated last =
-                        // highest internal number (the host puts the reference bus at nb-1)
-                        const int pin = 31 - __clz((int)R);
-                        // island rules 2-5 (DESIGN.md "island policy")
-                        uint32_t cnt = 0; double losum = 0.0; bool inI[IS];
-#pragma unroll
-                        for (int s = 0; s < IS; ++s) {
-                            const int j = 16 * s + rlane;
-                            const uint32_t kind = (iinfo[s] >> 8) & 0xff;
-                            inI[s] = I_ON(s) && ((R >> (iinfo[s] & 0xff)) & 1u);
-                            if (inI[s]) {
-                                cnt += 1u;
-                                if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
-                                losum += C.i_pmin_mw[j] * ISC(s);
+                for (int t = 0; t < BS; ++t) {
+                    const int i = RW * t + rlane;
+                    uint32_t adj = 0;
+                    if (i < nb) {
+                        const int nlb = C.b_nline[i];
+                        for (int e = 0; e < nlb; ++e) {
+                            const uint32_t ent = C.b_line[i][e];
+                            const int l = ent & 0x7f;
+                            if (!outbit(OB, ng + l)) {
+                                const uint32_t inf = C.l_info[l];
+                                adj |= 1u << ((ent & 0x80) ? (inf & 0xff) : ((inf >> 8) & 0xff));
                             }
                         }
-                        cnt = row_add(cnt); losum = row_sum(losum);
-                        const uint32_t n_inj = cnt & 0xff, n_load = (cnt >> 8) & 0xff, n_gen = cnt >> 16;
-                        if (n_inj && !n_load) {                  // rule 2: no load -> decommit the island's units
-#pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s]) { sf &= ~(1u << (6 + s)); inI[s] = false; }
-                            infeas = true;
-                        } else if (n_load && !n_gen) {           // rule 3: no generation -> all load shed (p fixed 0)
-#pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL) lozero |= 1u << s;
-                        } else if (losum > 1e-9) {               // rule 4: over-generation -> relax Pmin
-#pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_REAL) lozero |= 1u << s;
-                            infeas = true;
-                        }
-                        uint32_t nfree = 0;
-#pragma unroll
-                        for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[16 * s + rlane] - ILO(s) > 0.0) nfree += 1u;
-                        nfree = row_add(nfree);
-                        if (!nfree) dropped |= 1u << pin;        // rule 5: dependent balance rows
-                        pinned |= 1u << pin;
-                        remaining &= ~R;
+                        iso = iso || adj == 0;
                     }
+                    adjm[t] = adj;
+                }
+                // a bus without any in-service branch makes MATPOWER's KKT matrix exactly singular; the
+                // reference consumes the start point (mc_simulation.m:41,54)
+                singular = (a.policy == 0) && row_any<RW>(iso, lane);
+                if (!singular) {
+                    uint32_t remaining = C.exist_mask;
+                    for (int guard = 0; guard < NBT; ++guard) {
+                        const bool more = remaining != 0;
+                        if (!__any(more)) break;
+                        if (more) {
+                            uint32_t R = any_lout ? 1u << (__ffs((int)remaining) - 1) : remaining;
+                            for (int sweep = 0; sweep < NBT; ++sweep) {
+                                if (!__any(any_lout)) break;
+                                uint32_t c = 0;
+#pragma unroll
+                                for (int t = 0; t < BS; ++t) if ((R >> (RW * t + rlane)) & 1u) c |= adjm[t];
+                                const uint32_t Rn = R | row_or<RW>(c);
+                                const bool ch = Rn != R;
+                                R = Rn;
+                                if (!__any(ch)) break;
+                            }
+                            // rule 1: the island's angle reference is its bus that is eliminated last =
+                            // highest internal number (the host puts the reference bus at nb-1)
+                            const int pin = 31 - __clz((int)R);
+                            uint32_t cnt = 0; double losum = 0.0; bool inI[IS];
+#pragma unroll
+                            for (int s = 0; s < IS; ++s) {
+                                const int j = RW * s + rlane;
+                                const uint32_t kind = (iinfo[s] >> 8) & 0xff;
+                                inI[s] = I_ON(s) && ((R >> (iinfo[s] & 0xff)) & 1u);
+                                if (inI[s]) {
+                                    cnt += 1u;
+                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
+                                    losum += C.i_pmin_mw[j] * ISC(s);
+                                }
+                            }
+                            cnt = row_add<RW>(cnt); losum = row_sum<RW>(losum);
+                            const uint32_t n_inj = cnt & 0xff, n_load = (cnt >> 8) & 0xff, n_gen = cnt >> 16;
+                            if (n_inj && !n_load) {                  // rule 2: no load -> decommit the island's units
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s]) { sf &= ~(1u << (6 + s)); inI[s] = false; }
+                                infeas = true;
+                            } else if (n_load && !n_gen) {           // rule 3: no generation -> all load shed (p fixed 0)
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL) lozero |= 1u << s;
+                            } else if (losum > 1e-9) {               // rule 4: over-generation -> relax Pmin
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_REAL) lozero |= 1u << s;
+                                infeas = true;
+                            }
+                            uint32_t nfree = 0;
+#pragma unroll
+                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[RW * s + rlane] - ILO(s) > 0.0) nfree += 1u;
+                            nfree = row_add<RW>(nfree);
+                            if (!nfree) dropped |= 1u << pin;        // rule 5: dependent balance rows
+                            pinned |= 1u << pin;
+                            remaining &= ~R;
+                        }
+                    }
+                }
+#pragma unroll
+                for (int t = 0; t < BS; ++t) {
+                    const int i = RW * t + rlane;
+                    if ((pinned >> i) & 1u) sf |= 1u << (14 + t);
+                    if ((dropped >> i) & 1u) sf |= 1u << (16 + t);
+                }
+#pragma unroll
+                for (int s = 0; s < LS; ++s) {
+                    const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                    const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;    // block (hi, lo): rows of hi, columns of lo
+                    if (((pinned >> f) | (pinned >> t)) & 1u) sf |= 1u << (18 + s);
+                    if (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) sf |= 1u << (21 + s);
+                    if (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) sf |= 1u << (24 + s);
+                }
+            } else {
+                // one scenario per wavefront: bus sets live in LDS (the solver workspace is idle during this prologue):
+                // LB[i] = label of bus i = highest internal bus number of its island, BF[i] = 1 pinned | 2 dropped
+                static_assert(RW == 16 || RW == 64, "row width");
+                int* const LB = reinterpret_cast<int*>(W);
+                int* const BF = LB + NBT;
+                bool iso = false;
+#pragma unroll
+                for (int t = 0; t < BS; ++t) {
+                    const int i = RW * t + rlane;
+                    if (i < nb) {
+                        bool anyon = false;
+                        const int nlb = C.b_nline[i];
+                        for (int e = 0; e < nlb; ++e) if (!outbit(OB, ng + (C.b_line[i][e] & 0x7f))) anyon = true;
+                        iso = iso || !anyon;
+                        LB[i] = any_lout ? i : nb - 1;
+                        BF[i] = 0;
+                    }
+                }
+                singular = (a.policy == 0) && row_any<RW>(iso, lane);
+                RELOAD_FENCE();
+                if (!singular) {
+                    if (any_lout) {
+                        for (int sweep = 0; sweep < NBT; ++sweep) {      // max-label propagation over the in-service lines
+                            bool ch = false;
+#pragma unroll
+                            for (int s = 0; s < LS; ++s) {
+                                if (L_ON(s)) {
+                                    const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                                    const int lf = LB[f], lt = LB[t];
+                                    if (lf != lt) { ch = true; if (lf < lt) atomicMax(&LB[f], lt); else atomicMax(&LB[t], lf); }
+                                }
+                            }
+                            RELOAD_FENCE();
+                            if (!row_any<RW>(ch, lane)) break;
+                        }
+                    }
+                    int ilab[IS];
+#pragma unroll
+                    for (int s = 0; s < IS; ++s) ilab[s] = LB[iinfo[s] & 0xff];
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) {
+                        const int i = RW * t + rlane;
+                        uint64_t roots = __ballot(i < nb && LB[i] == i);
+                        while (roots) {
+                            const int pin = RW * t + (int)__builtin_ctzll(roots);      // rule 1: the island's highest bus
+                            roots &= roots - 1;
+                            uint32_t cnt = 0; double losum = 0.0; bool inI[IS];
+#pragma unroll
+                            for (int s = 0; s < IS; ++s) {
+                                const int j = RW * s + rlane;
+                                const uint32_t kind = (iinfo[s] >> 8) & 0xff;
+                                inI[s] = I_ON(s) && ilab[s] == pin;
+                                if (inI[s]) {
+                                    cnt += 1u;
+                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
+                                    losum += C.i_pmin_mw[j] * ISC(s);
+                                }
+                            }
+                            cnt = row_add<RW>(cnt); losum = row_sum<RW>(losum);
+                            const uint32_t n_inj = cnt & 0xff, n_load = (cnt >> 8) & 0xff, n_gen = cnt >> 16;
+                            if (n_inj && !n_load) {                  // rule 2
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s]) { sf &= ~(1u << (6 + s)); inI[s] = false; }
+                                infeas = true;
+                            } else if (n_load && !n_gen) {           // rule 3
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL) lozero |= 1u << s;
+                            } else if (losum > 1e-9) {               // rule 4
+#pragma unroll
+                                for (int s = 0; s < IS; ++s) if (inI[s] && ((iinfo[s] >> 8) & 0xff) == IK_REAL) lozero |= 1u << s;
+                                infeas = true;
+                            }
+                            uint32_t nfree = 0;
+#pragma unroll
+                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[RW * s + rlane] - ILO(s) > 0.0) nfree += 1u;
+                            nfree = row_add<RW>(nfree);
+#pragma unroll
+                            for (int u = 0; u < BS; ++u)
+                                if (RW * u + rlane == pin) { sf |= 1u << (14 + u); if (!nfree) sf |= 1u << (16 + u); }   // rules 1, 5
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) BF[RW * t + rlane] = (B_PIN(t) ? 1 : 0) | (B_DROP(t) ? 2 : 0);
+                    RELOAD_FENCE();
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) {
+                        if ((linfo[s] >> 24) & LF_EXISTS) {
+                            const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                            const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;
+                            const int flo = BF[lo_b], fhi = BF[hi_b];
+                            if ((flo | fhi) & 1) sf |= 1u << (18 + s);
+                            if ((fhi & 1) | (flo & 2)) sf |= 1u << (21 + s);
+                            if ((flo & 1) | (fhi & 2)) sf |= 1u << (24 + s);
+                        }
+                    }
+                    RELOAD_FENCE();
                 }
             }
 
@@ -355,24 +518,23 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             for (int s = 0; s < LS; ++s) {
                 const uint32_t inf = linfo[s];
                 if ((inf >> 24) & LF_OWNER) {
-                    const int f = inf & 0xff, t = (inf >> 8) & 0xff;
                     double v = L_ON(s) ? lb(s) : 0.0;
                     const int pr = lpart[s];
-                    if (pr >= 0 && !outbit(o0, o1, o2, o3, ng + pr)) v += C.l_b[pr];
+                    if (pr >= 0 && !outbit(OB, ng + pr)) v += C.l_b[pr];
                     cBv[s] = -v;                 // -(b_l + b_partner) of the in-service lines of this bus pair
                 }
             }
 #pragma unroll
             for (int t = 0; t < BS; ++t) {
-                const int i = 16 * t + rlane;
+                const int i = RW * t + rlane;
                 if (i < nb) {
                     double d = 0.0;
                     const int nlb = C.b_nline[i];
                     for (int e = 0; e < nlb; ++e) {
                         const int l = C.b_line[i][e] & 0x7f;
-                        if (!outbit(o0, o1, o2, o3, ng + l)) d += C.l_b[l];
+                        if (!outbit(OB, ng + l)) d += C.l_b[l];
                     }
-                    cBd[t] = (((pinned | dropped) >> i) & 1u) ? 0.0 : d;
+                    cBd[t] = (B_PIN(t) || B_DROP(t)) ? 0.0 : d;
                 }
             }
 
@@ -391,7 +553,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             }
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
-                const int j = 16 * s + rlane;
+                const int j = RW * s + rlane;
                 if (I_ON(s)) {
                     const double hi = C.i_hi[j], lo = ILO(s);
                     const bool box = hi - lo > eps;
@@ -408,9 +570,9 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BS; ++t) if (16 * t + rlane < nb) Lam[16 * t + rlane] = 0.0;
-            niq = row_add(nq);
-            fval = row_sum(fl);
+            for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) Lam[RW * t + rlane] = 0.0;
+            niq = row_add<RW>(nq);
+            fval = row_sum<RW>(fl);
             f0 = fval;
             iterating = !singular;
             status = singular ? 3 : 0;
@@ -427,7 +589,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 double gown[LS];
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
-                    const int l = 16 * s + rlane;
+                    const int l = RW * s + rlane;
                     double g = 0.0, lx = 0.0, q = 0.0;
                     if (L_ON(s)) {
                         lx = LGv[s];                 // G_l = b_l (lambda_f - lambda_t), carried incrementally
@@ -449,7 +611,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
-                    const int j = 16 * s + rlane;
+                    const int j = RW * s + rlane;
                     double invD = 0.0, npd = 0.0, pv = 0.0;
                     if (I_ON(s)) {
                         pv = ip[s];
@@ -469,7 +631,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         }
                     }
                     if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
-                    Stash[16 * (2 * s)] = invD; Stash[16 * (2 * s + 1)] = npd;
+                    Stash[RW * (2 * s)] = invD; Stash[RW * (2 * s + 1)] = npd;
                     SLOT_FENCE();
                 }
                 PT_MARK(1)
@@ -481,16 +643,15 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     vown[s] = 0.0;
                     const uint32_t inf = linfo[s];
                     if ((inf >> 24) & LF_OWNER) {
-                        const int f = inf & 0xff, t = (inf >> 8) & 0xff;
                         double gs = gown[s];
                         if (lpart[s] >= 0) gs += LR[4 * lpart[s]];
-                        vown[s] = (((pinned >> f) | (pinned >> t)) & 1u) ? 0.0 : -gs;   // pinned columns removed
+                        vown[s] = L_PIN(s) ? 0.0 : -gs;   // pinned columns removed
                     }
                 }
                 double d00[BS], d11[BS], r0[BS], r1[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = 16 * t + rlane;
+                    const int bi = RW * t + rlane;
                     d00[t] = 0; d11[t] = 0; r0[t] = 0; r1[t] = 0;
                     if (bi < nb) {
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
@@ -513,18 +674,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                         for (int e = 0; e < BINJMAX; ++e) {
                             if (e >= maxinj) break;
                             const uint32_t ent = (uint32_t)(pj >> (8 * e)) & 0xffu;
-                            const int j = ent == 0x7f ? nip : (int)ent;
+                            const int j = ent == 0xff ? nip : (int)ent;
                             const d2 ra = ld2(IR + 4 * j);
                             bal -= ra.x; E += ra.y; ssum += IR[4 * j + 2];
                         }
-                        if ((pinned >> bi) & 1u) {        // fixed angle: identity row; its multiplier is -lx
+                        if (B_PIN(t)) {                   // fixed angle: identity row; its multiplier is -lx
                             d00[t] = 1.0; r0[t] = 0.0;
                             mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(lx));
                         } else {
                             d00[t] = md; r0[t] = -nq_;
                             mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lx));
                         }
-                        if ((dropped >> bi) & 1u) {       // dependent balance row
+                        if (B_DROP(t)) {                  // dependent balance row
                             d11[t] = -1.0; r1[t] = 0.0;
                         } else {
                             d11[t] = -E; r1[t] = -bal - ssum;
@@ -540,18 +701,17 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     if ((linfo[s] >> 24) & LF_OWNER) {
-                        const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
-                        const int lo_b = f < t ? f : t, hi_b = f < t ? t : f;    // block (hi, lo): rows of hi, columns of lo
-                        const double c1 = (((pinned >> hi_b) | (dropped >> lo_b)) & 1u) ? 0.0 : cBv[s];   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
-                        const double c2 = (((pinned >> lo_b) | (dropped >> hi_b)) & 1u) ? 0.0 : cBv[s];   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
-                        double* blk = W + C.l_blk[16 * s + rlane];
+                        // block (hi, lo): rows of the later-eliminated bus, columns of the earlier one
+                        const double c1 = L_C1Z(s) ? 0.0 : cBv[s];   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
+                        const double c2 = L_C2Z(s) ? 0.0 : cBv[s];   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
+                        double* blk = W + C.l_blk[RW * s + rlane];
                         st2(blk, vown[s], c1); st2(blk + 2, c2, 0.0);
                     }
                 }
-                for (int z = rlane; z < nzero; z += ROWL) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
+                for (int z = rlane; z < nzero; z += RW) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = 16 * t + rlane;
+                    const int bi = RW * t + rlane;
                     if (bi < nb) {
                         st2(W + 4 * bi, d00[t], cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11[t]);
                         st2(W + off_rhs + 2 * bi, r0[t], r1[t]);
@@ -563,12 +723,21 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 // The four conditions must hold together, so the two that need only |x| (complementarity and
                 // cost change) are tested first; the other three row reductions run only when some scenario
                 // of the wavefront passes them (never before the last 2-3 iterations).
-                mx_x = row_max(mx_x);
-                const uint64_t nanb = __ballot(nanx);
-                const bool xnan = ((nanb >> (lane & 48)) & 0xffffull) != 0;
+                mx_x = row_max<RW>(mx_x);
+                const bool xnan = row_any<RW>(nanx, lane);
                 bool conv = it > 0 && zmu < a.comptol * (1.0 + mx_x) && __builtin_fabs(fval - f0) < a.costtol * (1.0 + __builtin_fabs(f0));
+#ifdef RELMC_TRACE
+                {   // debug builds: per-iteration termination quantities of scenario 0 (first launch row) -> a.timing as doubles
+                    const double t_gh = row_max<RW>(mx_gh), t_z = row_max<RW>(mx_z), t_lx = row_max<RW>(mx_lx), t_lm = row_max<RW>(mx_lammu);
+                    if (a.timing && blockIdx.x == 0 && tid == 0 && it < 60) {
+                        double* o = reinterpret_cast<double*>(a.timing) + 8 * it;
+                        o[0] = t_gh / (1.0 + __builtin_fmax(mx_x, t_z)); o[1] = t_lx / (1.0 + t_lm); o[2] = zmu / (1.0 + mx_x);
+                        o[3] = __builtin_fabs(fval - f0) / (1.0 + __builtin_fabs(f0)); o[4] = alphap; o[5] = alphad; o[6] = gamma; o[7] = fval;
+                    }
+                }
+#endif
                 if (__any(conv)) {
-                    mx_gh = row_max(mx_gh); mx_z = row_max(mx_z); mx_lx = row_max(mx_lx); mx_lammu = row_max(mx_lammu);
+                    mx_gh = row_max<RW>(mx_gh); mx_z = row_max<RW>(mx_z); mx_lx = row_max<RW>(mx_lx); mx_lammu = row_max<RW>(mx_lammu);
                     // feascond < feastol, gradcond < gradtol with the (positive) denominators multiplied out
                     conv = conv && mx_gh < a.feastol * (1.0 + __builtin_fmax(mx_x, mx_z)) && mx_lx < a.gradtol * (1.0 + mx_lammu);
                 }
@@ -657,7 +826,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 double dth[BS], dla[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = 16 * t + rlane;
+                    const int bi = RW * t + rlane;
                     dth[t] = 0; dla[t] = 0;
                     if (bi < nb) { const d2 x = ld2(X + 2 * bi); dth[t] = x.x; dla[t] = x.y; step2 = __builtin_fma(x.x, x.x, __builtin_fma(x.y, x.y, step2)); }
                 }
@@ -690,12 +859,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 double dpv[IS], dlb[IS];
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
-                    const int j = 16 * s + rlane;
+                    const int j = RW * s + rlane;
                     dpv[s] = 0; dlb[s] = 0;
                     if (I_ON(s)) {
                         dlb[s] = X[2 * (iinfo[s] & 0xff) + 1];
                         if (I_BOX(s)) {
-                            dpv[s] = __builtin_fma(dlb[s], Stash[16 * (2 * s)], -Stash[16 * (2 * s + 1)]);   // dp = (-Np + dlam)/D
+                            dpv[s] = __builtin_fma(dlb[s], Stash[RW * (2 * s)], -Stash[RW * (2 * s + 1)]);   // dp = (-Np + dlam)/D
                             const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
@@ -708,12 +877,12 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     }
                     SLOT_FENCE();
                 }
-                step2 = row_sum(step2);
+                step2 = row_sum<RW>(step2);
                 if (!(step2 <= a.max_stepsize * a.max_stepsize)) {
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
-                    tp = row_max(tp); td = row_max(td);
+                    tp = row_max<RW>(tp); td = row_max<RW>(td);
                     alphap = tp > 0.0 ? __builtin_fmin(a.xi * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
                     alphad = td > 0.0 ? __builtin_fmin(a.xi * frcp(td), 1.0) : 1.0;
                     double zl = 0.0, fl = 0.0;
@@ -738,7 +907,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                     for (int s = 0; s < IS; ++s) {
                         if (I_ON(s)) {
                             if (I_BOX(s)) {
-                                const int j = 16 * s + rlane;
+                                const int j = RW * s + rlane;
                                 const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                                 const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                                 const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
@@ -748,17 +917,17 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                                 imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
                                 zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                             }
-                            fl = __builtin_fma(C.i_cost[16 * s + rlane], ip[s], fl);
+                            fl = __builtin_fma(C.i_cost[RW * s + rlane], ip[s], fl);
                         }
                         SLOT_FENCE();
                     }
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
                         bth[t] = __builtin_fma(alphap, dth[t], bth[t]); bla[t] = __builtin_fma(alphad, dla[t], bla[t]);
-                        if (16 * t + rlane < nb) Lam[16 * t + rlane] = bla[t];
+                        if (RW * t + rlane < nb) Lam[RW * t + rlane] = bla[t];
                     }
-                    zmu = row_sum(zl);
-                    fval = row_sum(fl);
+                    zmu = row_sum<RW>(zl);
+                    fval = row_sum<RW>(fl);
                     if (niq > 0) gamma = a.sigma * zmu / (double)niq;
                 }
                 PT_MARK(6)
@@ -774,18 +943,18 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             double shed[IS];
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
-                const int j = 16 * s + rlane;
+                const int j = RW * s + rlane;
                 shed[s] = 0.0;
                 if (((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL && dns > 0.0) {
                     const double v = ip[s] * base - C.i_pmin_mw[j] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
                 if (shed[s] != 0.0) PA.shed[s] += shed[s];
-                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(o0, o1, o2, o3, j)) PA.cf_inj[s] += 1;
+                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += 1;
             }
 #pragma unroll
             for (int s = 0; s < LS; ++s)
-                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(o0, o1, o2, o3, ng + 16 * s + rlane)) PA.cf_line[s] += 1;
+                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += 1;
             if (rlane == 0) {                       // row-uniform quantities: one lane per scenario row
                 PA.n += 1;
                 if (dns != 0.0) { PA.dns += dns; PA.dns2 = __builtin_fma(dns, dns, PA.dns2); }
@@ -798,7 +967,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
             if (MODE == 1) {
 #pragma unroll
-                for (int s = 0; s < IS; ++s) if (16 * s + rlane < nip) IR[4 * (16 * s + rlane)] = shed[s];
+                for (int s = 0; s < IS; ++s) if (RW * s + rlane < nip) IR[4 * (RW * s + rlane)] = shed[s];
                 if (rlane == 0) {
                     a.dns[sidx] = dns;
                     if (a.status) a.status[sidx] = status;
@@ -807,7 +976,7 @@ __global__ void __launch_bounds__(64 * WPB, RELMC_MIN_WAVES) relmc_eval_kernel(c
                 if (a.nodal) {
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
-                        const int i = 16 * t + rlane;
+                        const int i = RW * t + rlane;
                         if (i < nb) {
                             const int vj = C.b_vinj[i];
                             a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? IR[4 * vj] : 0.0;
@@ -831,11 +1000,14 @@ struct DevAcc {
 
 constexpr int FIN_ITEMS = 8 + 256 + 128;
 
-// One workgroup (one wavefront) per output element; the 16-lane rows are summed lane-strided and
+// One workgroup (one wavefront) per output element; the scenario rows are summed lane-strided and
 // combined by a fixed butterfly, so the accumulators are bit-reproducible for a launch geometry.
-__global__ void __launch_bounds__(64) relmc_finalize_kernel(const DevCase* __restrict__ C, const Partial* __restrict__ part,
+template <class TL>
+__global__ void __launch_bounds__(64) relmc_finalize_kernel(const DevCaseT<TL>* __restrict__ C, const PartialT<TL>* __restrict__ part,
                                                             int nrows, DevAcc* __restrict__ out)
 {
+    constexpr int RW = TL::RW;
+    using Partial = PartialT<TL>;
     const int item = blockIdx.x, lane = threadIdx.x;
     long long si = 0; double sd = 0.0;
     bool is_int = true; int ln = 0, sl = 0, field = 0;   // field: 0..5 counters, 6 dns, 7 dns2, 8 cf_inj, 9 cf_line, 10 shed
@@ -844,18 +1016,18 @@ __global__ void __launch_bounds__(64) relmc_finalize_kernel(const DevCase* __res
     else if (item < 8) { field = item; is_int = false; }
     else if (item < 8 + 256) {
         const int k = item - 8;
-        if (k < C->ncomp) { const bool isgen = k < C->ng; const int idx = isgen ? k : k - C->ng; ln = idx & 15; sl = idx >> 4; field = isgen ? 8 : 9; }
+        if (k < C->ncomp) { const bool isgen = k < C->ng; const int idx = isgen ? k : k - C->ng; ln = idx % RW; sl = idx / RW; field = isgen ? 8 : 9; }
         else active = false;
     } else {
         const int i = item - 8 - 256;                  // external bus number
         const int ii = i < C->nb ? C->b_int[i] : -1;
         is_int = false;
-        if (ii >= 0 && C->b_vinj[ii] >= 0) { const int j = C->b_vinj[ii]; ln = j & 15; sl = j >> 4; field = 10; }
+        if (ii >= 0 && C->b_vinj[ii] >= 0) { const int j = C->b_vinj[ii]; ln = j % RW; sl = j / RW; field = 10; }
         else active = false;
     }
     if (active) {
         for (int r = lane; r < nrows; r += 64) {
-            const Partial& p = part[(size_t)r * 16 + ln];
+            const Partial& p = part[(size_t)r * RW + ln];
             switch (field) {
                 case 0: si += p.n; break; case 1: si += p.nfail; break; case 2: si += p.nsing; break;
                 case 3: si += p.ninf; break; case 4: si += p.nnc; break; case 5: si += p.iters; break;
@@ -878,7 +1050,8 @@ __global__ void __launch_bounds__(64) relmc_finalize_kernel(const DevCase* __res
 }
 
 // mc_sampling.m:2 materialised: eqstatus[n x ncomp] uint8, one thread per (scenario, 4-component block)
-__global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCase* __restrict__ C, uint64_t seed, uint64_t first_index,
+template <class TL>
+__global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index,
                                                              int64_t n, uint8_t* __restrict__ eqstatus)
 {
     const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2;
@@ -898,6 +1071,7 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCase* __re
 }
 
 // ---- sequential track (Montecarlo_seq/): chronology sampling, contingency-hour compaction, annual indices ----
+constexpr int NCOMPMAX = 128;       // component capacity of the sequential chronology and of the HL1 fleet tables
 struct SeqCase {
     int32_t ncomp, hpy;
     double mttf[NCOMPMAX], mttr[NCOMPMAX];
@@ -1045,10 +1219,10 @@ __global__ void relmc_dpp_probe_kernel(const double* __restrict__ in, double* __
     const int t = threadIdx.x;
     const double v = in[t];
     out[t] = dppd<0x150 + 5>(v);
-    out[64 + t] = row_sum(v);
-    out[128 + t] = row_max(v);
-    out[192 + t] = row_min(v);
-    out[256 + t] = (double)row_or(1u << (t & 15));
+    out[64 + t] = row_sum<16>(v);
+    out[128 + t] = row_max<16>(v);
+    out[192 + t] = row_min<16>(v);
+    out[256 + t] = (double)row_or<16>(1u << (t & 15));
     out[320 + t] = frcp(v);
     { const double r0 = __builtin_amdgcn_rcp(v); out[384 + t] = r0; const double e = __builtin_fma(-v, r0, 1.0); out[448 + t] = __builtin_fma(r0, e, r0); }
 }
