@@ -32,6 +32,9 @@ def main():
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
     ap.add_argument("--batch", type=int, default=1_000_000, help="scenarios per GPU per step")
+    ap.add_argument("--workload", choices=["nsq24", "rts96", "seq"], default="nsq24",
+                    help="nsq24 = BASELINE configs[1] (the headline, default); rts96 = configs[4] shape; seq = configs[3] shape")
+    ap.add_argument("--years", type=int, default=125, help="seq workload: simulated years per GPU per step")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -55,6 +58,8 @@ def main():
     if world > 1:
         dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
 
+    if args.workload != "nsq24":
+        return secondary_workload(args, world, rank, local_rank, device)
     case = case24.rts24()
     eng = api.Engine(case, device=local_rank)
     policy = api.REFERENCE_EMULATE if args.policy == "emulate" else api.PHYSICAL
@@ -109,7 +114,8 @@ def main():
             "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
                          "frac": achieved / FP64_PEAK_TFLOPS, "traffic": hbm_traffic_from_profile(B),
                          "kernel": "relmc_eval_kernel<0>", "kernel_ms_avg": avg_kernel_s * 1e3,
-                         "algorithmic_flop_per_scenario": flop_per_scen, "mean_ipm_iterations": idx["mean_iters"]},
+                         "algorithmic_flop_per_scenario": flop_per_scen, "mean_ipm_iterations": idx["mean_iters"],
+                         "executed_flop_per_iteration_sparse_schedule": sparse_flop_per_iteration(eng, case)},
             "indices": {"n": n_total, "edns_mw": idx["edns"], "lole_h_per_yr": idx["lole"], "plc": idx["plc"],
                         "beta": idx["beta"], "n_singular": int(total.n_singular),
                         "n_nonconverged": int(total.n_nonconverged)},
@@ -124,6 +130,96 @@ def main():
                                        "batch": 100_000, "converged": r.converged}
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+def sparse_flop_per_iteration(eng, case):
+    """Floating-point operations one Newton iteration of the shipped sparse solver executes per scenario: the static
+    schedule's task counts (43 flop per 2x2 block update, 29 per right-hand-side update, 21 per pivot inversion, 14 per
+    back-substitution task) plus the per-element work on lines, injections and buses (about 60 / 70 / 30 flop each)."""
+    import ctypes as C
+    out = (C.c_int32 * 9)()
+    eng.L.relmc_debug_schedule(eng._h, out)
+    noff, ntask = out[3], out[8]
+    nblock = ntask - case.nb - 2 * noff
+    return 43.0 * nblock + 29.0 * noff + 21.0 * case.nb + 14.0 * noff + 60.0 * case.nl + 70.0 * case.ninj + 30.0 * case.nb
+
+
+def secondary_workload(args, world, rank, local_rank, device):
+    """The two other GPU configurations of BASELINE.json, same timing contract, one JSON line:
+       rts96: non-sequential MCS on the 73-bus RTS-96 (one scenario per wavefront tile), --batch scenarios per GPU per step;
+       seq:   sequential MCS on RTS-24, --years simulated years per GPU per step (8736 hourly states each, only the
+              contingency hours are evaluated, seqMain.m:97), annual indices all-gathered per step."""
+    import numpy as np
+    import torch
+    import torch.distributed as dist
+    from powersystemsreliabilityassessment_amd import api, case24, case96, dist as rdist, seq as rseq
+
+    def sync():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank])
+        torch.cuda.synchronize()
+
+    if args.workload == "rts96":
+        case = case96.rts96()
+        eng = api.Engine(case, device=local_rank)
+        B = args.batch
+        opts = api.mpoption(api.REFERENCE_EMULATE)
+
+        def step(k):
+            acc = eng.nsq_accumulate(args.seed, (k * world + rank) * B, B, opts)
+            ms = eng.last_kernel_ms()
+            return rdist.allreduce_acc(acc, device), ms, B
+        unit, metric = "scenarios/s", "Monte Carlo DC-OPF scenarios/sec (RTS-96 HL2 non-sequential)"
+        workload = f"HL2 non-sequential MCS, IEEE RTS-96 (73 buses, 120 branches, 99 generator rows) DC-OPF load shedding, {B} samples per GPU per step (BASELINE configs[4] shape)"
+    else:
+        case = case24.rts24()
+        eng = api.Engine(case, device=local_rank)
+        sq = rseq.SeqEngine(eng)
+        Y = args.years
+
+        def step(k):
+            e, d, n_, ncont, acc = sq.seq_years(args.seed, (k * world + rank) * Y, Y)
+            ms = eng.last_kernel_ms()
+            rdist.allgather_years(np.column_stack([e, d, n_]), [Y] * world, device)
+            return rdist.allreduce_acc(acc, device), ms, int(acc.n)
+        unit, metric = "hourly DC-OPFs/s", "Monte Carlo hourly DC-OPF evaluations/sec (RTS-24 HL2 sequential)"
+        workload = f"HL2 sequential MCS, RTS-24, {Y} simulated years x 8736 h per GPU per step, contingency hours only (BASELINE configs[3] shape)"
+
+    for k in range(args.warmup):
+        step(k)
+    sync()
+    t0 = time.perf_counter()
+    total, kernel_ms, units_rank = None, [], 0
+    for k in range(args.steps):
+        acc, ms, u = step(args.warmup + k)
+        kernel_ms.append(ms); units_rank += u
+        total = acc if total is None else rdist.merge(total, acc)
+    sync()
+    elapsed = time.perf_counter() - t0
+    if world > 1:
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device)
+        dist.all_reduce(t, op=dist.ReduceOp.MAX)
+        elapsed = float(t.item())
+    if rank == 0:
+        n_total = int(total.n)
+        mean_iters = total.sum_iters / n_total
+        fl = sparse_flop_per_iteration(eng, case)
+        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) * 1e-3
+        achieved = (units_rank / args.steps) * mean_iters * fl / avg_kernel_s / 1e12
+        out = {"metric": metric, "value": n_total / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+               "dtype": "f64", "data": "synthetic",
+               "config": {"workload": workload, "seed": args.seed, "parallelism": f"index / year sharding x{world}, accumulators all-reduced per step"},
+               "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
+                            "traffic": None, "kernel": "relmc_eval_kernel", "kernel_ms_avg": avg_kernel_s * 1e3,
+                            "flop_model": "operations of the sparse block LDL' schedule + per-element work (bench.sparse_flop_per_iteration); "
+                                          "SURVEY 8d's dense count would exceed the peak on this workload",
+                            "flop_per_iteration": fl, "mean_ipm_iterations": mean_iters},
+               "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "loss_fraction": total.n_fail / n_total,
+                           "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged)}}
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()
