@@ -33,10 +33,14 @@ DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf
 template <int CTRL>
 DEVFI uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true); }
 
+// max / min as the single hardware instruction: __builtin_fmax would first canonicalise both inputs (two extra
+// v_max_f64 x, x, x per call); the instruction already returns the non-NaN operand, which is the fmax semantics
+DEVFI double vmax(double a, double b) { double r; __asm__("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
+DEVFI double vmin(double a, double b) { double r; __asm__("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
 // all-reduce over the 16 lanes of a DPP row (row_ror 8,4,2,1); every lane gets bit-identical results
 DEVFI double row16_sum(double v) { v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v); return v; }
-DEVFI double row16_max(double v) { v = __builtin_fmax(v, dppd<0x128>(v)); v = __builtin_fmax(v, dppd<0x124>(v)); v = __builtin_fmax(v, dppd<0x122>(v)); v = __builtin_fmax(v, dppd<0x121>(v)); return v; }
-DEVFI double row16_min(double v) { v = __builtin_fmin(v, dppd<0x128>(v)); v = __builtin_fmin(v, dppd<0x124>(v)); v = __builtin_fmin(v, dppd<0x122>(v)); v = __builtin_fmin(v, dppd<0x121>(v)); return v; }
+DEVFI double row16_max(double v) { v = vmax(v, dppd<0x128>(v)); v = vmax(v, dppd<0x124>(v)); v = vmax(v, dppd<0x122>(v)); v = vmax(v, dppd<0x121>(v)); return v; }
+DEVFI double row16_min(double v) { v = vmin(v, dppd<0x128>(v)); v = vmin(v, dppd<0x124>(v)); v = vmin(v, dppd<0x122>(v)); v = vmin(v, dppd<0x121>(v)); return v; }
 DEVFI uint32_t row16_or(uint32_t v) { v |= dppu<0x128>(v); v |= dppu<0x124>(v); v |= dppu<0x122>(v); v |= dppu<0x121>(v); return v; }
 DEVFI uint32_t row16_add(uint32_t v) { v += dppu<0x128>(v); v += dppu<0x124>(v); v += dppu<0x122>(v); v += dppu<0x121>(v); return v; }
 
@@ -58,13 +62,13 @@ template <int RW> DEVFI double row_sum(double v)
 template <int RW> DEVFI double row_max(double v)
 {
     v = row16_max(v);
-    if constexpr (RW == 64) v = __builtin_fmax(__builtin_fmax(rdlane(v, 0), rdlane(v, 16)), __builtin_fmax(rdlane(v, 32), rdlane(v, 48)));
+    if constexpr (RW == 64) v = vmax(vmax(rdlane(v, 0), rdlane(v, 16)), vmax(rdlane(v, 32), rdlane(v, 48)));
     return v;
 }
 template <int RW> DEVFI double row_min(double v)
 {
     v = row16_min(v);
-    if constexpr (RW == 64) v = __builtin_fmin(__builtin_fmin(rdlane(v, 0), rdlane(v, 16)), __builtin_fmin(rdlane(v, 32), rdlane(v, 48)));
+    if constexpr (RW == 64) v = vmin(vmin(rdlane(v, 0), rdlane(v, 16)), vmin(rdlane(v, 32), rdlane(v, 48)));
     return v;
 }
 template <int RW> DEVFI uint32_t row_or(uint32_t v)
@@ -155,17 +159,24 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     using DevCase = DevCaseT<TL>;
     using Partial = PartialT<TL>;
     extern __shared__ __attribute__((aligned(16))) unsigned char smem[];
-    DevCase& C = *reinterpret_cast<DevCase*>(smem);
+    // solver options live in the first 128 bytes of LDS and are read where they are used: as kernel arguments they
+    // would occupy ~20 SGPRs for the whole kernel and come back from spill lanes as 16-register tuples
+    constexpr uint32_t OPT_BYTES = 128;
+    volatile double* const OPT = reinterpret_cast<volatile double*>(smem);
+#define A_(k, name) OPT[k]
+    DevCase& C = *reinterpret_cast<DevCase*>(smem + OPT_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, rlane = lane & (RW - 1), row = tid / RW;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)gcase->npass + 1u) * (uint32_t)sizeof(C.task[0]);   // +1: descriptor prefetch
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(gcase);
-        uint32_t* dst = reinterpret_cast<uint32_t*>(smem);
+        uint32_t* dst = reinterpret_cast<uint32_t*>(smem + OPT_BYTES);
+        if (tid == 0) { OPT[0] = a.feastol; OPT[1] = a.gradtol; OPT[2] = a.comptol; OPT[3] = a.costtol; OPT[4] = a.xi; OPT[5] = a.sigma;
+                        OPT[6] = a.z0; OPT[7] = a.alpha_min; OPT[8] = a.max_stepsize; OPT[9] = a.fail_threshold; }
         for (uint32_t i = tid; i < case_bytes / 4; i += 64 * WPB) dst[i] = src[i];
     }
     __syncthreads();
     const int nws = (int)C.nws;
-    double* const W = reinterpret_cast<double*>(smem + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
+    double* const W = reinterpret_cast<double*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
     // The evaluation arrays ALIAS the solver workspace: they are dead once the bus gathers have been
     // taken into registers, and only then are the KKT blocks written (see "assemble" below).
     // line record l = {g, lx, q, F} at LR + 4l, injection record j = {p, 1/D, Np/D, -} at IR + 4j; record nl / ninj
@@ -545,8 +556,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             for (int s = 0; s < LS; ++s) {
                 if (L_ACT(s)) {
                     const double h = -lr(s);                       // x0: all angles 0 -> flow 0
-                    double z = a.z0; if (h < -a.z0) z = -h;
-                    double mu = a.z0; if (1.0 / z > a.z0) mu = 1.0 / z;
+                    double z = A_(6, z0); if (h < -A_(6, z0)) z = -h;
+                    double mu = A_(6, z0); if (1.0 / z > A_(6, z0)) mu = 1.0 / z;
                     lzp[s] = z; lzm[s] = z; lmup[s] = mu; lmum[s] = mu;
                     nq += 2;
                 }
@@ -561,8 +572,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     ip[s] = box ? 0.5 * (lo + hi) : hi;
                     if (box) {
                         const double h = -0.5 * (hi - lo);
-                        double z = a.z0; if (h < -a.z0) z = -h;
-                        double mu = a.z0; if (1.0 / z > a.z0) mu = 1.0 / z;
+                        double z = A_(6, z0); if (h < -A_(6, z0)) z = -h;
+                        double mu = A_(6, z0); if (1.0 / z > A_(6, z0)) mu = 1.0 / z;
                         izp[s] = z; izm[s] = z; imup[s] = mu; imum[s] = mu;
                         nq += 2;
                     }
@@ -600,9 +611,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
                             lx = __builtin_fma(b, lmup[s] - lmum[s], lx);
                             q = b * ((lmup[s] * hp + gamma) * rzp - (lmum[s] * hm + gamma) * rzm);
-                            mx_gh = __builtin_fmax(mx_gh, __builtin_fmax(hp, hm));
-                            mx_z = __builtin_fmax(mx_z, __builtin_fmax(lzp[s], lzm[s]));
-                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(lmup[s], lmum[s]));
+                            mx_gh = vmax(mx_gh, vmax(hp, hm));
+                            mx_z = vmax(mx_z, vmax(lzp[s], lzm[s]));
+                            mx_lammu = vmax(mx_lammu, vmax(lmup[s], lmum[s]));
                         }
                     }
                     gown[s] = g;
@@ -615,7 +626,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     double invD = 0.0, npd = 0.0, pv = 0.0;
                     if (I_ON(s)) {
                         pv = ip[s];
-                        mx_x = __builtin_fmax(mx_x, __builtin_fabs(pv));
+                        mx_x = vmax(mx_x, __builtin_fabs(pv));
                         nanx = nanx || pv != pv;
                         if (I_BOX(s)) {
                             const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
@@ -624,10 +635,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const double lxp = C.i_cost[j] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                             const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
                             invD = frcp(D); npd = np * invD;
-                            mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lxp));
-                            mx_gh = __builtin_fmax(mx_gh, __builtin_fmax(hp, hm));
-                            mx_z = __builtin_fmax(mx_z, __builtin_fmax(izp[s], izm[s]));
-                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fmax(imup[s], imum[s]));
+                            mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
+                            mx_gh = vmax(mx_gh, vmax(hp, hm));
+                            mx_z = vmax(mx_z, vmax(izp[s], izm[s]));
+                            mx_lammu = vmax(mx_lammu, vmax(imup[s], imum[s]));
                         }
                     }
                     if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
@@ -680,19 +691,19 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         }
                         if (B_PIN(t)) {                   // fixed angle: identity row; its multiplier is -lx
                             d00[t] = 1.0; r0[t] = 0.0;
-                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(lx));
+                            mx_lammu = vmax(mx_lammu, __builtin_fabs(lx));
                         } else {
                             d00[t] = md; r0[t] = -nq_;
-                            mx_lx = __builtin_fmax(mx_lx, __builtin_fabs(lx));
+                            mx_lx = vmax(mx_lx, __builtin_fabs(lx));
                         }
                         if (B_DROP(t)) {                  // dependent balance row
                             d11[t] = -1.0; r1[t] = 0.0;
                         } else {
                             d11[t] = -E; r1[t] = -bal - ssum;
-                            mx_gh = __builtin_fmax(mx_gh, __builtin_fabs(bal));
-                            mx_lammu = __builtin_fmax(mx_lammu, __builtin_fabs(bla[t]));
+                            mx_gh = vmax(mx_gh, __builtin_fabs(bal));
+                            mx_lammu = vmax(mx_lammu, __builtin_fabs(bla[t]));
                         }
-                        mx_x = __builtin_fmax(mx_x, __builtin_fabs(bth[t]));
+                        mx_x = vmax(mx_x, __builtin_fabs(bth[t]));
                         nanx = nanx || bth[t] != bth[t];
                     }
                 }
@@ -725,13 +736,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 // of the wavefront passes them (never before the last 2-3 iterations).
                 mx_x = row_max<RW>(mx_x);
                 const bool xnan = row_any<RW>(nanx, lane);
-                bool conv = it > 0 && zmu < a.comptol * (1.0 + mx_x) && __builtin_fabs(fval - f0) < a.costtol * (1.0 + __builtin_fabs(f0));
+                bool conv = it > 0 && zmu < A_(2, comptol) * (1.0 + mx_x) && __builtin_fabs(fval - f0) < A_(3, costtol) * (1.0 + __builtin_fabs(f0));
 #ifdef RELMC_TRACE
                 {   // debug builds: per-iteration termination quantities of scenario 0 (first launch row) -> a.timing as doubles
                     const double t_gh = row_max<RW>(mx_gh), t_z = row_max<RW>(mx_z), t_lx = row_max<RW>(mx_lx), t_lm = row_max<RW>(mx_lammu);
                     if (a.timing && blockIdx.x == 0 && tid == 0 && it < 60) {
                         double* o = reinterpret_cast<double*>(a.timing) + 8 * it;
-                        o[0] = t_gh / (1.0 + __builtin_fmax(mx_x, t_z)); o[1] = t_lx / (1.0 + t_lm); o[2] = zmu / (1.0 + mx_x);
+                        o[0] = t_gh / (1.0 + vmax(mx_x, t_z)); o[1] = t_lx / (1.0 + t_lm); o[2] = zmu / (1.0 + mx_x);
                         o[3] = __builtin_fabs(fval - f0) / (1.0 + __builtin_fabs(f0)); o[4] = alphap; o[5] = alphad; o[6] = gamma; o[7] = fval;
                     }
                 }
@@ -739,7 +750,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 if (__any(conv)) {
                     mx_gh = row_max<RW>(mx_gh); mx_z = row_max<RW>(mx_z); mx_lx = row_max<RW>(mx_lx); mx_lammu = row_max<RW>(mx_lammu);
                     // feascond < feastol, gradcond < gradtol with the (positive) denominators multiplied out
-                    conv = conv && mx_gh < a.feastol * (1.0 + __builtin_fmax(mx_x, mx_z)) && mx_lx < a.gradtol * (1.0 + mx_lammu);
+                    conv = conv && mx_gh < A_(0, feastol) * (1.0 + vmax(mx_x, mx_z)) && mx_lx < A_(1, gradtol) * (1.0 + mx_lammu);
                 }
 #ifdef RELMC_ABLATE_FIXIT
                 if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }
@@ -747,7 +758,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #else
                 if (conv) { status = 0; iterating = false; }
 #endif
-                else if (it > 0 && (xnan || alphap < a.alpha_min || alphad < a.alpha_min || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
+                else if (it > 0 && (xnan || alphap < A_(7, alpha_min) || alphad < A_(7, alpha_min) || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
             }
             PT_MARK(3)
@@ -850,8 +861,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
                             const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
                             // ratio tests without divisions by the steps: min_k z_k/(-dz_k) = 1 / max_k(-dz_k/z_k)
-                            tp = __builtin_fmax(tp, __builtin_fmax(-dzp * rzp, -dzm * rzm));
-                            td = __builtin_fmax(td, __builtin_fmax(-dmup * frcp1(lmup[s]), -dmum * frcp1(lmum[s])));
+                            tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
+                            td = vmax(td, vmax(-dmup * frcp1(lmup[s]), -dmum * frcp1(lmum[s])));
                         }
                     }
                     SLOT_FENCE();
@@ -870,21 +881,21 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
                             const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
-                            tp = __builtin_fmax(tp, __builtin_fmax(-dzp * rzp, -dzm * rzm));
-                            td = __builtin_fmax(td, __builtin_fmax(-dmup * frcp1(imup[s]), -dmum * frcp1(imum[s])));
+                            tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
+                            td = vmax(td, vmax(-dmup * frcp1(imup[s]), -dmum * frcp1(imum[s])));
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
                     SLOT_FENCE();
                 }
                 step2 = row_sum<RW>(step2);
-                if (!(step2 <= a.max_stepsize * a.max_stepsize)) {
+                if (!(step2 <= A_(8, max_stepsize) * A_(8, max_stepsize))) {
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
                     tp = row_max<RW>(tp); td = row_max<RW>(td);
-                    alphap = tp > 0.0 ? __builtin_fmin(a.xi * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
-                    alphad = td > 0.0 ? __builtin_fmin(a.xi * frcp(td), 1.0) : 1.0;
+                    alphap = tp > 0.0 ? vmin(A_(4, xi) * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
+                    alphad = td > 0.0 ? vmin(A_(4, xi) * frcp(td), 1.0) : 1.0;
                     double zl = 0.0, fl = 0.0;
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
@@ -928,7 +939,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     zmu = row_sum<RW>(zl);
                     fval = row_sum<RW>(fl);
-                    if (niq > 0) gamma = a.sigma * zmu / (double)niq;
+                    if (niq > 0) gamma = A_(5, sigma) * zmu / (double)niq;
                 }
                 PT_MARK(6)
             }
