@@ -38,6 +38,7 @@ def main():
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-time-to-cov", action="store_true", help="skip the nsqMain run (profiling: only identical 1e6 launches)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="scenarios of the CPU baseline sample (0 = auto)")
     args = ap.parse_args()
 
@@ -121,7 +122,7 @@ def main():
                         "n_nonconverged": int(total.n_nonconverged)},
         }
         # wall-time to EENS CoV < 1 % (second half of BASELINE.json's metric), single GPU loop of nsqMain
-        if world == 1:
+        if world == 1 and not args.no_time_to_cov:
             t1 = time.perf_counter()
             r = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000,
                             seed=args.seed, mpopt=opts)
@@ -226,20 +227,17 @@ def secondary_workload(args, world, rank, local_rank, device):
 
 
 def hbm_traffic_from_profile(batch):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes
-    (profiles/*/pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this
-    command, gfx950 correction applied); scaled to this batch.  None if no profile is committed."""
-    import glob
-    best = None
-    for f in sorted(glob.glob(os.path.join(ROOT, "profiles", "*", "pmc_summary.json"))):
-        try:
-            with open(f) as fh:
-                t = json.load(fh).get("hbm_traffic")
-            if t:
-                best = t["bytes_per_scenario"] * batch
-        except (OSError, ValueError, KeyError):
-            pass
-    return best
+    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of the profile named in
+    profiles/current.txt (pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this command, gfx950
+    correction applied); scaled to this batch.  None if no profile is committed."""
+    try:
+        with open(os.path.join(ROOT, "profiles", "current.txt")) as fh:
+            name = fh.read().strip()
+        with open(os.path.join(ROOT, "profiles", name, "pmc_summary.json")) as fh:
+            t = json.load(fh).get("hbm_traffic")
+        return t["bytes_per_scenario"] * batch if t else None
+    except (OSError, ValueError, KeyError):
+        return None
 
 
 def cpu_baseline(case, policy, seed, n_sample):

@@ -1,0 +1,53 @@
+#!/usr/bin/env python3
+"""Turns the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>/) into the committed summary
+profiles/<name>/{kernel_stats.csv, pmc_summary.json, bench_line.json}:   python scripts/summarize_profile.py <tag> <name>"""
+import collections, csv, glob, json, os, shutil, sys
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+tag, name = sys.argv[1], sys.argv[2]
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+dst = os.path.join(ROOT, "profiles", name)
+os.makedirs(dst, exist_ok=True)
+
+stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
+if stats:
+    shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+summary = {}
+for p in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
+    f = glob.glob(os.path.join(src, p, "**", "*counter_collection.csv"), recursive=True)
+    if not f:
+        continue
+    per = collections.defaultdict(lambda: collections.defaultdict(float))
+    disp = collections.defaultdict(set)
+    for r in csv.DictReader(open(f[0])):
+        k = r["Kernel_Name"].split("(")[0]
+        per[k][r["Counter_Name"]] += float(r["Counter_Value"])
+        disp[k].add(r["Dispatch_Id"])
+    for k, v in per.items():
+        summary.setdefault(k, {})[p] = {"dispatches": len(disp[k]), "sums": dict(v)}
+line = None
+for lg in ("trace_bench.log", "pmc_sq.log"):
+    try:
+        for ln in open(os.path.join(src, lg)):
+            if ln.startswith("{") and '"metric"' in ln:
+                line = json.loads(ln)
+                if lg == "trace_bench.log":
+                    json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
+                break
+    except OSError:
+        pass
+    if lg == "pmc_sq.log" and line:
+        n_pmc = line["indices"]["n"] + 0
+        # the PMC command is `bench.py --steps 1 --warmup 0 --no-time-to-cov`: exactly one 1e6-scenario launch
+        ttc = line.get("time_to_cov_1pct", {}).get("samples", 0)
+        scen = n_pmc + ttc
+        ev = [k for k in summary if "eval_kernel" in k]
+        if ev and "pmc_fetch" in summary[ev[0]] and "pmc_write" in summary[ev[0]]:
+            fk = summary[ev[0]]["pmc_fetch"]["sums"]["FETCH_SIZE"]; wk = summary[ev[0]]["pmc_write"]["sums"]["WRITE_SIZE"]
+            b = (2.0 * fk + wk) * 1024.0
+            summary["hbm_traffic"] = {
+                "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-time-to-cov` (one 1e6-scenario launch); units KiB; FETCH_SIZE "
+                        "doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads), WRITE_SIZE uncalibrated",
+                "fetch_kib": fk, "write_kib": wk, "scenarios": scen, "bytes_per_scenario": b / scen, "bytes_per_1e6_scenario_launch": b / scen * 1e6}
+json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+print("wrote", dst, sorted(os.listdir(dst)))
