@@ -137,6 +137,9 @@ typedef struct {
     double* edns_history;
     double* lole_history;
     double* plc_history;
+    int32_t distinct_states;  /* 1: evaluate every distinct state of a batch once and count multiplicities, the
+                                 reference's unique-state database (nsqMain.m:220-245) per batch; 0 (default): solve
+                                 every sample.  The estimators are identical. */
 } relmc_nsq_opts;
 
 typedef struct {
@@ -183,6 +186,11 @@ int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64
 int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
                              const relmc_solver_opts* opts, relmc_acc* acc_out);
 /* HIP-event duration (ms) of the most recent fused / simulation kernel on the ctx stream */
+/* The same accumulators through the reference's dedupe (nsqMain.m:220-245): sample the range, sort the outage masks on
+ * the device, evaluate each distinct state once weighted by its multiplicity.  *n_distinct_out (optional) = states solved.
+ * relmc_last_kernel_ms then covers sampling + sort + evaluation. */
+int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
+                                      const relmc_solver_opts* opts, relmc_acc* acc_out, int64_t* n_distinct_out);
 int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
 
 /* ---- estimators (host arithmetic, no device) ---------------------------------------- */

@@ -93,6 +93,7 @@ class NsqOpts(C.Structure):
         ("history_cap", C.c_int64),
         ("beta_history", c_double_p), ("edns_history", c_double_p),
         ("lole_history", c_double_p), ("plc_history", c_double_p),
+        ("distinct_states", C.c_int32),
     ]
 
 

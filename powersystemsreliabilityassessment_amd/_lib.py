@@ -20,7 +20,7 @@ EXPORTS = [
     "relmc_ctx_create", "relmc_ctx_destroy", "relmc_last_error", "relmc_version",
     "relmc_solver_opts_default", "relmc_nsq_opts_default", "relmc_case_load",
     "relmc_case_thresholds", "relmc_mc_sampling", "relmc_mc_sampling_dev",
-    "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate",
+    "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate", "relmc_nsq_accumulate_distinct",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years",
@@ -86,6 +86,9 @@ def load():
     L.relmc_nsq_accumulate.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts),
                                        C.POINTER(_abi.Acc)]
     L.relmc_nsq_accumulate.restype = C.c_int32
+    L.relmc_nsq_accumulate_distinct.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts),
+                                                C.POINTER(_abi.Acc), C.POINTER(C.c_int64)]
+    L.relmc_nsq_accumulate_distinct.restype = C.c_int32
     L.relmc_last_kernel_ms.argtypes = [vp, _abi.c_double_p]
     L.relmc_last_kernel_ms.restype = C.c_int32
     L.relmc_acc_zero.argtypes = [C.POINTER(_abi.Acc)]

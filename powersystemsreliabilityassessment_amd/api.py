@@ -190,6 +190,16 @@ class Engine:
                                                 C.byref(acc)), "relmc_nsq_accumulate")
         return acc
 
+    def nsq_accumulate_distinct(self, seed: int, first_index: int, n: int, mpopt=None):
+        """The same accumulators through the reference's dedupe (nsqMain.m:220-245): every distinct state of the range is
+        solved once and counted with its multiplicity.  Returns (Acc, number of distinct states)."""
+        o = mpopt if mpopt is not None else mpoption()
+        acc = _abi.Acc()
+        nd = C.c_int64()
+        self._check(self.L.relmc_nsq_accumulate_distinct(self._h, int(seed), int(first_index), int(n), C.byref(o), C.byref(acc),
+                                                         C.byref(nd)), "relmc_nsq_accumulate_distinct")
+        return acc, int(nd.value)
+
     def last_kernel_ms(self) -> float:
         ms = C.c_double()
         self._check(self.L.relmc_last_kernel_ms(self._h, C.byref(ms)), "relmc_last_kernel_ms")
@@ -203,13 +213,14 @@ class Engine:
     # -- nsqMain.m:208-406 ---------------------------------------------------------------------
     def nsqMain(self, beta_limit: float = 0.0017, max_iterations: int = 100000,
                 samples_per_batch: int = 100, *, seed: int = 1, mpopt=None,
-                hours_per_year: float = 8760.0) -> NsqResult:
+                hours_per_year: float = 8760.0, distinct_states: bool = False) -> NsqResult:
         """Defaults are the reference's (nsqMain.m:60-62).  On a GPU a batch of 100 is tiny; pass
         samples_per_batch >= 1e5 for throughput — the estimators do not depend on the batch size."""
         o = _abi.NsqOpts()
         self.L.relmc_nsq_opts_default(C.byref(o))
         o.beta_limit, o.max_samples, o.batch = float(beta_limit), int(max_iterations), int(samples_per_batch)
         o.seed, o.hours_per_year = int(seed), float(hours_per_year)
+        o.distinct_states = 1 if distinct_states else 0           # the reference's unique-state database, per batch
         if mpopt is not None:
             o.solver = mpopt
         ncp = (int(max_iterations) + int(samples_per_batch) - 1) // int(samples_per_batch)

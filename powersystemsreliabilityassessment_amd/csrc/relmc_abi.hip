@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstddef>
 
+#include <rocprim/rocprim.hpp>
+
 #include "../../include/relmc.h"
 #include "relmc_kernels.hip"
 
@@ -38,6 +40,10 @@ struct relmc_ctx {
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
     unsigned long long* dtiming = nullptr; int timing_waves = 0;
+    // distinct-state path: device buffers sized for memo_cap samples
+    int64_t memo_cap = 0; size_t memo_tmp_bytes = 0;
+    uint32_t *mk = nullptr, *mperm0 = nullptr, *mperm1 = nullptr, *mhead = nullptr, *muid = nullptr, *mstart = nullptr, *mnu = nullptr;
+    unsigned long long *mch0 = nullptr, *mch1 = nullptr; void* mtmp = nullptr;
     // sequential track
     bool has_seq = false; SeqCase hseq; SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
@@ -377,6 +383,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, TL>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
     ctx->blocks_per_cu = bpc;
@@ -426,6 +433,8 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (!ctx) return;
     (void)hipSetDevice(ctx->device);
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
+    for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
+                    (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
     if (ctx->dcase) (void)hipFree(ctx->dcase);
     if (ctx->dacc) (void)hipFree(ctx->dacc);
     if (ctx->dhl1) (void)hipFree(ctx->dhl1);
@@ -609,6 +618,93 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
         done += m;
     }
     ctx->last_kernel_ms = ms_total;
+    return RELMC_OK;
+}
+
+// nsqMain.m:220-245 per launch: the sampled range's distinct states are evaluated once each and counted with their
+// multiplicities.  Same accumulators as relmc_nsq_accumulate (integers identical, sums up to summation order).
+int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
+                                      relmc_acc* acc_out, int64_t* n_distinct_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_accumulate_distinct: no case loaded");
+    if (n < 0 || !acc_out) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_accumulate_distinct: bad arguments");
+    relmc_acc_zero(acc_out);
+    if (n_distinct_out) *n_distinct_out = 0;
+    if (n == 0) return RELMC_OK;
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int64_t kMaxPerLaunch = (int64_t)1 << 27;      // 32-bit weighted counters per scenario row
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int nchunk = (ctx->ncomp + 63) / 64;
+    double ms_total = 0.0;
+    int64_t distinct_total = 0;
+    for (int64_t done = 0; done < n;) {
+        const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
+        size_t tmp_sort = 0, tmp_scan = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (size_t)m, 0u, 64u, ctx->stream);
+        (void)rocprim::exclusive_scan(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream);
+        const size_t tmp_need = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+        if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
+            for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
+                            (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
+            ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
+            ctx->memo_cap = 0; ctx->memo_tmp_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->mk, sizeof(uint32_t) * (size_t)m * 8));
+            HIP_TRY(ctx, hipMalloc(&ctx->mperm0, sizeof(uint32_t) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->mperm1, sizeof(uint32_t) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->mhead, sizeof(uint32_t) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->muid, sizeof(uint32_t) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->mstart, sizeof(uint32_t) * ((size_t)m + 1)));
+            HIP_TRY(ctx, hipMalloc(&ctx->mnu, sizeof(uint32_t)));
+            HIP_TRY(ctx, hipMalloc(&ctx->mch0, sizeof(unsigned long long) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->mch1, sizeof(unsigned long long) * (size_t)m));
+            HIP_TRY(ctx, hipMalloc(&ctx->mtmp, tmp_need));
+            ctx->memo_cap = m; ctx->memo_tmp_bytes = tmp_need;
+        }
+        int64_t gb = (m + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
+        const dim3 grid((unsigned)gb), blk(256);
+        const auto t0 = std::chrono::steady_clock::now();
+        if (ctx->tile == 0) hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile24>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index + (uint64_t)done, m, ctx->mk);
+        else hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile96>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index + (uint64_t)done, m, ctx->mk);
+        hipLaunchKernelGGL(relmc_memo_iota_kernel, grid, blk, 0, ctx->stream, m, ctx->mperm0);
+        uint32_t* pin = ctx->mperm0; uint32_t* pout = ctx->mperm1;
+        for (int c = 0; c < nchunk; ++c) {               // LSD: stable sort by chunk 0, then 1, ...
+            hipLaunchKernelGGL(relmc_memo_chunk_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, c, m, ctx->mch0);
+            const int bits = ctx->ncomp - 64 * c < 64 ? ctx->ncomp - 64 * c : 64;
+            size_t tb = ctx->memo_tmp_bytes;
+            HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->mtmp, tb, ctx->mch0, ctx->mch1, pin, pout, (size_t)m, 0u, (unsigned)bits, ctx->stream));
+            uint32_t* t = pin; pin = pout; pout = t;
+        }
+        hipLaunchKernelGGL(relmc_memo_heads_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, m, ctx->mhead);
+        { size_t tb = ctx->memo_tmp_bytes;
+          HIP_TRY(ctx, rocprim::exclusive_scan(ctx->mtmp, tb, ctx->mhead, ctx->muid, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream)); }
+        hipLaunchKernelGGL(relmc_memo_starts_kernel, grid, blk, 0, ctx->stream, ctx->mhead, ctx->muid, m, ctx->mstart, ctx->mnu);
+        HIP_TRY(ctx, hipGetLastError());
+        uint32_t nu = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&nu, ctx->mnu, sizeof(nu), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        const double prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        EvalArgs a = make_args(o);
+        a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
+        int rows = 0;
+        int rc = launch_eval<3>(ctx, a, &rows);
+        if (rc) return rc;
+        rc = launch_finalize(ctx, rows);
+        if (rc) return rc;
+        relmc_acc part;
+        HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
+        rc = finish_timing(ctx);
+        if (rc) return rc;
+        ms_total += ctx->last_kernel_ms + prep_ms;       // sampling + sort + run-length encoding (host-timed) + evaluation kernel
+        relmc_acc_merge(acc_out, &part);
+        distinct_total += nu;
+        done += m;
+    }
+    ctx->last_kernel_ms = ms_total;
+    if (n_distinct_out) *n_distinct_out = distinct_total;
     return RELMC_OK;
 }
 
@@ -887,7 +983,8 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     while (beta > o->beta_limit && done < o->max_samples) {
         const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;
         relmc_acc part;
-        int rc = relmc_nsq_accumulate(ctx, o->seed, (uint64_t)done, m, &o->solver, &part);
+        int rc = o->distinct_states ? relmc_nsq_accumulate_distinct(ctx, o->seed, (uint64_t)done, m, &o->solver, &part, nullptr)
+                                    : relmc_nsq_accumulate(ctx, o->seed, (uint64_t)done, m, &o->solver, &part);
         if (rc) return rc;
         kernel_ms += ctx->last_kernel_ms;
         relmc_acc_merge(&res->acc, &part);

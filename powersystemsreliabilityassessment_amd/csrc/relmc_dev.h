@@ -121,6 +121,11 @@ struct EvalArgs {
     const double* load_factors;     // [hours]
     double* curt;                   // [years][hours] hourly curtailment (MW), zero where not evaluated
     int32_t seq_nyears, seq_hpy;
+    // MODE 3 (distinct states with multiplicities, nsqMain.m:220-245): scenario u = state memo_keys[memo_perm[memo_start[u]]]
+    // counted memo_start[u+1] - memo_start[u] times
+    const uint32_t* memo_keys;      // [n][OW] outage masks of the sampled range
+    const uint32_t* memo_perm;      // [n] sample indices sorted by mask
+    const uint32_t* memo_start;     // [n_distinct + 1] first sorted position of every distinct mask
 };
 
 }  // namespace relmc

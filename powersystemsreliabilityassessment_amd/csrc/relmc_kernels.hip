@@ -152,6 +152,8 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 // MODE 1: explicit states (+ optional per-scenario load scale), per-scenario results written out
 // MODE 2: sequential path: scenarios = compacted (year, hour) worklist, states from the chronology bit masks,
 //         load scale from the hourly curve, curtailment written to curt[year][hour]
+// MODE 3: distinct states of a sampled range with their multiplicities (the reference's unique-state database,
+//         nsqMain.m:220-245, per launch): accumulators are weighted by the multiplicity
 template <int MODE, class TL>
 __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
@@ -225,6 +227,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         const int64_t sidx = grp * SPW + lane / RW;
         const bool live = sidx < a.n;
         double lscale = 1.0;                 // load_scale_factor of seq_mcsimulation.m:38-42 (1 in the non-sequential path)
+        uint32_t wgt = 1;                    // multiplicity of the state (MODE 3)
         int seq_year = 0, seq_hour = 0;
         RELOAD_FENCE();
 
@@ -274,6 +277,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 const uint32_t* m = a.seq_masks + ((size_t)seq_year * a.seq_hpy + seq_hour) * 4;
                 if (rlane < OW) OB[rlane] = rlane < 4 ? m[rlane] : 0u;
                 lscale = a.load_factors[seq_hour];            // seqMain.m:114
+            } else if (MODE == 3) {
+                const uint32_t s0 = a.memo_start[sidx];
+                wgt = a.memo_start[sidx + 1] - s0;
+                if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)a.memo_perm[s0] * OW + rlane];
             } else {
                 if (rlane < OW) OB[rlane] = 0u;
                 RELOAD_FENCE();
@@ -960,20 +967,23 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     const double v = ip[s] * base - C.i_pmin_mw[j] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
-                if (shed[s] != 0.0) PA.shed[s] += shed[s];
-                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += 1;
+                if (shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
+                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += wgt;
             }
 #pragma unroll
             for (int s = 0; s < LS; ++s)
-                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += 1;
+                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
             if (rlane == 0) {                       // row-uniform quantities: one lane per scenario row
-                PA.n += 1;
-                if (dns != 0.0) { PA.dns += dns; PA.dns2 = __builtin_fma(dns, dns, PA.dns2); }
-                if (fail) PA.nfail += 1;
-                if (status == 3) PA.nsing += 1;
-                if (status == 1 || status == 2) PA.nnc += 1;
-                if (infeas) PA.ninf += 1;
-                PA.iters += (uint32_t)it;
+                PA.n += wgt;
+                if (dns != 0.0) {
+                    if (MODE == 3) { PA.dns = __builtin_fma((double)wgt, dns, PA.dns); PA.dns2 = __builtin_fma((double)wgt * dns, dns, PA.dns2); }
+                    else { PA.dns += dns; PA.dns2 = __builtin_fma(dns, dns, PA.dns2); }
+                }
+                if (fail) PA.nfail += wgt;
+                if (status == 3) PA.nsing += wgt;
+                if (status == 1 || status == 2) PA.nnc += wgt;
+                if (infeas) PA.ninf += wgt;
+                PA.iters += (uint32_t)it * wgt;
             }
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
             if (MODE == 1) {
@@ -1082,6 +1092,73 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCaseT<TL>*
 }
 
 // ---- sequential track (Montecarlo_seq/): chronology sampling, contingency-hour compaction, annual indices ----
+// ---- distinct-state path (nsqMain.m:220-245): masks of a sampled range, sorted and run-length encoded on the device ----
+// one thread per scenario: the same draws as relmc_sampling_kernel / MODE 0, packed as OW mask words
+template <class TL>
+__global__ void __launch_bounds__(256) relmc_memo_keys_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index,
+                                                              int64_t n, uint32_t* __restrict__ keys)
+{
+    constexpr int OW = TL::OW;
+    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint64_t gi = first_index + (uint64_t)i;
+        uint32_t w[OW];
+#pragma unroll
+        for (int q = 0; q < OW; ++q) w[q] = 0;
+        for (int blk = 0; blk < nblk; ++blk) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            uint32_t nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
+#pragma unroll
+            for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
+        }
+#pragma unroll
+        for (int q = 0; q < OW; ++q) keys[(size_t)i * OW + q] = w[q];
+    }
+}
+
+// 64-bit chunk c of the masks in the current order (LSD radix passes, least significant chunk first)
+__global__ void __launch_bounds__(256) relmc_memo_chunk_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int ow, int c,
+                                                               int64_t n, unsigned long long* __restrict__ out)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t* kp = keys + (size_t)perm[j] * ow + 2 * c;
+        out[j] = (unsigned long long)kp[0] | ((unsigned long long)kp[1] << 32);
+    }
+}
+
+__global__ void __launch_bounds__(256) relmc_memo_iota_kernel(int64_t n, uint32_t* __restrict__ perm)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) perm[j] = (uint32_t)j;
+}
+
+// head[j] = 1 when sorted position j starts a new distinct mask
+__global__ void __launch_bounds__(256) relmc_memo_heads_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int ow, int64_t n,
+                                                               uint32_t* __restrict__ head)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        uint32_t h = 1;
+        if (j > 0) {
+            const uint32_t* ka = keys + (size_t)perm[j] * ow; const uint32_t* kb = keys + (size_t)perm[j - 1] * ow;
+            h = 0;
+            for (int q = 0; q < ow; ++q) h |= (ka[q] != kb[q]) ? 1u : 0u;
+        }
+        head[j] = h;
+    }
+}
+
+// start[u] = first sorted position of distinct mask u; start[n_distinct] = n; *n_distinct_out = number of distinct masks
+__global__ void __launch_bounds__(256) relmc_memo_starts_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ uid, int64_t n,
+                                                                uint32_t* __restrict__ start, uint32_t* __restrict__ n_distinct_out)
+{
+    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
+        if (head[j]) start[uid[j]] = (uint32_t)j;
+        if (j == n - 1) { const uint32_t nu = uid[j] + head[j]; start[nu] = (uint32_t)n; *n_distinct_out = nu; }
+    }
+}
+
 constexpr int NCOMPMAX = 128;       // component capacity of the sequential chronology and of the HL1 fleet tables
 struct SeqCase {
     int32_t ncomp, hpy;

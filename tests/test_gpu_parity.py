@@ -169,3 +169,22 @@ def test_full_size_properties(engine, golden):
     # weak-point statistic that identifies the reference's isolated-bus artifact: importance(L11) ~ 0.004
     assert 0.003 < ix.comp_importance[33 + 10] < 0.005
     assert 12.0 < ix.mean_iters < 12.5
+
+
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_distinct_state_path_equals_per_sample_path(engine, policy):
+    """nsqMain.m:220-245 on the device (sort the outage masks, solve each distinct state once, weight by multiplicity)
+    gives the accumulators of the per-sample path: integers identical, sums up to summation order."""
+    n, seed, first = 300000, 3, 10**9
+    plain = engine.nsq_accumulate(seed, first, n, api.mpoption(policy))
+    acc, nd = engine.nsq_accumulate_distinct(seed, first, n, api.mpoption(policy))
+    pi, pd = plain.to_arrays(); ai, ad = acc.to_arrays()
+    assert np.array_equal(ai, pi)
+    np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
+    assert 0.03 * n < nd < 0.15 * n                       # SURVEY 8f rank 4: 9.2 % distinct at 1e5, 2.9 % at 2e6
+    # the run loop with the option set walks the same beta curve
+    a = engine.nsqMain(beta_limit=0.02, max_iterations=400000, samples_per_batch=50000, seed=2, mpopt=api.mpoption(policy))
+    b = engine.nsqMain(beta_limit=0.02, max_iterations=400000, samples_per_batch=50000, seed=2, mpopt=api.mpoption(policy), distinct_states=True)
+    assert a.current_iteration == b.current_iteration and a.plc == b.plc
+    np.testing.assert_allclose(b.beta_history, a.beta_history, rtol=1e-9)
+    assert b.accumulated_edns == pytest.approx(a.accumulated_edns, rel=1e-12)

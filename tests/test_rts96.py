@@ -146,3 +146,14 @@ def test_gpu96_run_to_convergence(engine96, case96_):
     assert r.plc > plc_lb - 4 * se
     assert r.accumulated_edns > exact.eue_mwh_yr - 4 * r.current_beta * r.accumulated_edns
     assert np.all(np.asarray(r.nodal_eens)[[10, 11, 16, 20, 21, 22, 23, 72]] == 0)      # buses without load never shed
+
+
+@pytest.mark.gpu
+def test_gpu96_distinct_state_path(engine96):
+    n = 200000
+    plain = engine96.nsq_accumulate(9, 0, n)
+    acc, nd = engine96.nsq_accumulate_distinct(9, 0, n)
+    pi, pd = plain.to_arrays(); ai, ad = acc.to_arrays()
+    np.testing.assert_array_equal(ai, pi)
+    np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
+    assert 0 < nd <= n
