@@ -121,6 +121,14 @@ function nsq_accumulate(eng::Engine, seed::Integer, first_index::Integer, n::Int
     return acc
 end
 
+"The reference's unique-state database (nsqMain.m:220-245) per range: every distinct state solved once, weighted by its count."
+function nsq_accumulate_distinct(eng::Engine, seed::Integer, first_index::Integer, n::Integer, mpopt::SolverOpts=mpoption())
+    acc = Acc(); nd = Ref{Int64}(0)
+    check(ccall((:relmc_nsq_accumulate_distinct, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int64, Ref{SolverOpts}, Ref{Acc}, Ref{Int64}),
+                eng.h, seed, first_index, n, mpopt, acc, nd), eng.h, "relmc_nsq_accumulate_distinct")
+    return acc, nd[]
+end
+
 function indices(eng::Engine, acc::Acc; hours_per_year=8760.0)
     out = Indices()
     ccall((:relmc_nsq_indices, LIB), Cvoid, (Ref{Acc}, Int32, Int32, Cdouble, Ref{Indices}),
@@ -129,13 +137,13 @@ function indices(eng::Engine, acc::Acc; hours_per_year=8760.0)
 end
 
 "nsqMain: `while beta > beta_limit && n < max_iterations` (nsqMain.m:208-318) + post-processing (:345-376)."
-function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption())
+function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption(), distinct_states=false)
     total = Acc(); ccall((:relmc_acc_zero, LIB), Cvoid, (Ref{Acc},), total)
     done = 0; beta = Inf; idx = Indices()
     beta_history = Float64[]; edns_history = Float64[]
     while beta > beta_limit && done < max_iterations
         m = min(samples_per_batch, max_iterations - done)
-        part = nsq_accumulate(eng, seed, done, m, mpopt)
+        part = distinct_states ? nsq_accumulate_distinct(eng, seed, done, m, mpopt)[1] : nsq_accumulate(eng, seed, done, m, mpopt)
         ccall((:relmc_acc_merge, LIB), Cvoid, (Ref{Acc}, Ref{Acc}), total, part)
         done += m
         idx = indices(eng, total); beta = idx.beta
