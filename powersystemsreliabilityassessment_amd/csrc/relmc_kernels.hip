@@ -164,7 +164,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // solver options live in the first 128 bytes of LDS and are read where they are used: as kernel arguments they
     // would occupy ~20 SGPRs for the whole kernel and come back from spill lanes as 16-register tuples
     constexpr uint32_t OPT_BYTES = 128;
-    volatile double* const OPT = reinterpret_cast<volatile double*>(smem);
+    double* const OPT = reinterpret_cast<double*>(smem);
 #define A_(k, name) OPT[k]
     DevCase& C = *reinterpret_cast<DevCase*>(smem + OPT_BYTES);
     const int tid = threadIdx.x, lane = tid & 63, rlane = lane & (RW - 1), row = tid / RW;
