@@ -400,7 +400,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.2 (gfx950; 16-lane DPP-row IPM, sparse 2x2-block LDL' in LDS, static schedule)"; }
+const char* relmc_version(void) { return "relmc 0.3 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedule)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
