@@ -188,3 +188,35 @@ def test_distinct_state_path_equals_per_sample_path(engine, policy):
     assert a.current_iteration == b.current_iteration and a.plc == b.plc
     np.testing.assert_allclose(b.beta_history, a.beta_history, rtol=1e-9)
     assert b.accumulated_edns == pytest.approx(a.accumulated_edns, rel=1e-12)
+
+
+def test_full_size_properties_1e6(engine):
+    """BASELINE configs[1] size (1e6 samples): size-independent properties instead of an oracle run.
+    (a) copper-sheet bound per state: dns >= max(0, load - available capacity), equality for ~99.9 % of the states
+        (SURVEY 4.1c), and dns <= load;  (b) sharding the index range 8 ways reproduces the 1-way accumulators;
+    (c) the accumulators equal the sums of the per-state outputs."""
+    from powersystemsreliabilityassessment_amd import dist
+    n, seed = 1_000_000, 1
+    case = engine.case
+    st = engine.mc_sampling(None, n, seed=seed, first_index=0)
+    dns = np.zeros(n); status = np.zeros(n, dtype=np.int32)
+    for lo in range(0, n, 250_000):
+        d, _, info = engine.mc_simulation(st[lo:lo + 250_000], mpopt=api.mpoption(api.PHYSICAL), return_info=True)
+        dns[lo:lo + 250_000] = d; status[lo:lo + 250_000] = info["status"]
+    cap = case.inj_pmax[:case.ng].sum() - st[:, :case.ng].astype(np.float64) @ case.inj_pmax[:case.ng]
+    bound = np.maximum(0.0, case.total_load - cap)
+    bound[bound < 0.1] = 0.0                                    # the 0.1 MW noise filter of mc_simulation.m:57
+    assert np.all(dns >= bound - 1e-5) and np.all(dns <= case.total_load + 1e-6)
+    assert np.mean(np.abs(dns - bound) < 1e-5) > 0.995
+    assert np.all(status == 0)
+    whole = engine.nsq_accumulate(seed, 0, n, api.mpoption(api.PHYSICAL))
+    merged = _abi.Acc()
+    for r in range(8):
+        lo, cnt = dist.shard_range(0, n, r, 8)
+        merged = dist.merge(merged, engine.nsq_accumulate(seed, lo, cnt, api.mpoption(api.PHYSICAL)))
+    wi, wd = whole.to_arrays(); mi, md = merged.to_arrays()
+    assert np.array_equal(wi, mi)
+    np.testing.assert_allclose(md, wd, rtol=1e-11, atol=1e-7)
+    assert whole.n == n and whole.n_fail == int((dns > 1e-4).sum())
+    assert whole.sum_dns == pytest.approx(dns.sum(), rel=1e-11)
+    np.testing.assert_array_equal(np.array(whole.comp_fail[:case.ncomp]), st[dns > 1e-4].sum(0))
