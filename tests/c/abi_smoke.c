@@ -1,0 +1,39 @@
+/* Plain-C client of include/relmc.h: proves the boundary is a C ABI (no C++ types, no Python).
+ * Usage: abi_smoke <case.bin>   (case arrays written by tests/test_c_abi.py)  -> prints "n n_fail sum_dns n_distinct" */
+#include <stdio.h>
+#include <stdlib.h>
+#include <string.h>
+#include "relmc.h"
+
+static void* rd(FILE* f, size_t bytes) { void* p = malloc(bytes); if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short read\n"); exit(2); } return p; }
+
+int main(int argc, char** argv)
+{
+    if (argc < 2) return 2;
+    FILE* f = fopen(argv[1], "rb");
+    if (!f) return 2;
+    int32_t hdr[5];                                   /* nb ng nl nd ref_bus */
+    double dd[2];                                     /* base_mva total_load */
+    if (fread(hdr, sizeof(int32_t), 5, f) != 5 || fread(dd, sizeof(double), 2, f) != 2) return 2;
+    relmc_case_desc d;
+    memset(&d, 0, sizeof(d));
+    d.nb = hdr[0]; d.ng = hdr[1]; d.nl = hdr[2]; d.nd = hdr[3]; d.ref_bus = hdr[4]; d.base_mva = dd[0]; d.total_load = dd[1];
+    const int ninj = d.ng + d.nd, ncomp = d.ng + d.nl;
+    d.bus_pd = rd(f, 8 * d.nb); d.inj_bus = rd(f, 4 * ninj); d.inj_pmin = rd(f, 8 * ninj); d.inj_pmax = rd(f, 8 * ninj); d.inj_cost = rd(f, 8 * ninj);
+    d.br_from = rd(f, 4 * d.nl); d.br_to = rd(f, 4 * d.nl); d.br_b = rd(f, 8 * d.nl); d.br_rate = rd(f, 8 * d.nl);
+    d.unavail = rd(f, 8 * ncomp); d.always_up = rd(f, ncomp);
+    fclose(f);
+    relmc_ctx* ctx = NULL;
+    if (relmc_ctx_create(0, &ctx) != RELMC_OK) { fprintf(stderr, "no device\n"); return 3; }
+    if (relmc_case_load(ctx, &d) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 4; }
+    relmc_solver_opts o; relmc_solver_opts_default(&o);
+    relmc_acc acc, acc2; int64_t nd = 0;
+    if (relmc_nsq_accumulate(ctx, 1, 0, 100000, &o, &acc) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 5; }
+    if (relmc_nsq_accumulate_distinct(ctx, 1, 0, 100000, &o, &acc2, &nd) != RELMC_OK) return 6;
+    if (acc.n != acc2.n || acc.n_fail != acc2.n_fail) return 7;
+    uint8_t st[4 * 256]; double dns[4];
+    if (relmc_mc_sampling(ctx, 1, 0, 4, st) != RELMC_OK || relmc_mc_simulation(ctx, st, 4, &o, dns, NULL, NULL, NULL) != RELMC_OK) return 8;
+    printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
+    relmc_ctx_destroy(ctx);
+    return 0;
+}
