@@ -177,7 +177,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         for (uint32_t i = tid; i < case_bytes / 4; i += 64 * WPB) dst[i] = src[i];
     }
     __syncthreads();
-    const int nws = (int)C.nws;
     double* const W = reinterpret_cast<double*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
     // The evaluation arrays ALIAS the solver workspace: they are dead once the bus gathers have been
     // taken into registers, and only then are the KKT blocks written (see "assemble" below).
