@@ -155,4 +155,84 @@ function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples
             comp_importance=collect(idx.comp_importance[1:nc]), beta_history=beta_history, edns_history=edns_history)
 end
 
+# ---- sequential track (Montecarlo_seq/) and HL1 copper sheet (GeneratingAdequacy/PowerSystemAdequacy.jl) ----------------
+
+struct SeqYear
+    ens::Cdouble; dlc::Cdouble; nlc::Cdouble; n_contingency::Int64
+end
+
+"relmc_seq_load: `reliability_data` = seqmeantime() [(Ng+Nl) x 2] = [MTTF MTTR]; `load_scale_factors` = anloducurve(hours)[3]."
+function seq_load(eng::Engine, reliability_data::AbstractMatrix, load_scale_factors::Vector{Float64})
+    mttf = Vector{Float64}(reliability_data[:, 1]); mttr = Vector{Float64}(reliability_data[:, 2])
+    check(ccall((:relmc_seq_load, LIB), Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Ptr{Cdouble}),
+                eng.h, mttf, mttr, length(load_scale_factors), load_scale_factors), eng.h, "relmc_seq_load")
+end
+
+"state_duration_matrix = seq_mcsampling(reliability_data, Ng, Nl, num_years, hours_per_year): (Ng+Nl) x (years*hours), 1 = down."
+function seq_mcsampling(eng::Engine, num_years::Integer, hours_per_year::Integer; seed::Integer=1, first_year::Integer=0)
+    ncomp = eng.sys.ng + eng.sys.nl
+    out = Matrix{UInt8}(undef, ncomp, num_years * hours_per_year)
+    check(ccall((:relmc_seq_mcsampling, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int32, Ptr{UInt8}),
+                eng.h, seed, first_year, num_years, out), eng.h, "relmc_seq_mcsampling")
+    return out
+end
+
+"[curtailment_mw, nodal] = seq_mcsimulation(component_status, load_scale_factor, ...), batched: states n x (Ng+Nl), scales n."
+function seq_mcsimulation(eng::Engine, component_status::AbstractMatrix, load_scale_factor::Vector{Float64}, mpopt::SolverOpts=mpoption())
+    n = size(component_status, 1)
+    st = Matrix{UInt8}(permutedims(component_status .!= 0))
+    dns = Vector{Float64}(undef, n); nodal = Matrix{Float64}(undef, eng.sys.nb, n)
+    check(ccall((:relmc_seq_mcsimulation, LIB), Int32,
+                (Ptr{Cvoid}, Ptr{UInt8}, Ptr{Cdouble}, Int64, Ref{SolverOpts}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
+                eng.h, st, load_scale_factor, n, mpopt, dns, nodal, C_NULL, C_NULL), eng.h, "relmc_seq_mcsimulation")
+    return dns, permutedims(nodal)
+end
+
+"Body of the `for iYear` loop (seqMain.m:85-176) for years [first_year, first_year + n_years), fused on the GPU."
+function seq_years(eng::Engine, seed::Integer, first_year::Integer, n_years::Integer, mpopt::SolverOpts=mpoption(); curtail_threshold=0.01)
+    yrs = Vector{SeqYear}(undef, n_years); acc = Acc()
+    check(ccall((:relmc_seq_years, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int32, Ref{SolverOpts}, Cdouble, Ptr{SeqYear}, Ref{Acc}),
+                eng.h, seed, first_year, n_years, mpopt, curtail_threshold, yrs, acc), eng.h, "relmc_seq_years")
+    return yrs, acc
+end
+
+"seqMain (seqMain.m:85-262): annual indices until CoV(EENS) < cov_threshold."
+function seqMain(eng::Engine; max_sim_years=4000, cov_threshold=0.05, seed=1, mpopt=mpoption(), batch_years=64)
+    ens = Float64[]; dlc = Float64[]; nlc = Float64[]; cum_eens = Float64[]; cum_cov = Float64[]
+    done = 0; stop = false
+    while done < max_sim_years && !stop
+        m = min(batch_years, max_sim_years - done)
+        yrs, _ = seq_years(eng, seed, done, m, mpopt)
+        for y in yrs
+            push!(ens, y.ens); push!(dlc, y.dlc); push!(nlc, y.nlc)
+            k = length(ens); mu = sum(ens) / k
+            cov = (k > 1 && mu > 0) ? sqrt(sum((ens .- mu) .^ 2) / (k - 1)) / (mu * sqrt(k)) : 0.0     # seqMain.m:183-185
+            push!(cum_eens, mu); push!(cum_cov, cov)
+            if k > 1 && 0 < cov < cov_threshold                                                   # :194
+                stop = true; break
+            end
+        end
+        done += m
+    end
+    k = length(ens)
+    return (final_year=k, eens=cum_eens[end], cov=cum_cov[end], lole=sum(dlc[1:k]) / k, lolf=sum(nlc[1:k]) / k,
+            results_year=(ens=ens, dlc=dlc, nlc=nlc), results_cum=(eens=cum_eens, cov=cum_cov))
+end
+
+mutable struct Hl1Acc
+    n::Int64; sum_lole::Cdouble; sum_eue::Cdouble; sum_lole2::Cdouble; sum_eue2::Cdouble
+    Hl1Acc() = new()
+end
+
+"run_non_sequential_mc (PowerSystemAdequacy.jl:169-208): one fleet state per iteration swept over the hourly load curve."
+function run_non_sequential_mc(eng::Engine, capacity::Vector{Float64}, for_rate::Vector{Float64}, hourly_load::Vector{Float64},
+                               n_iterations::Integer; seed::Integer=1)
+    check(ccall((:relmc_hl1_load, LIB), Int32, (Ptr{Cvoid}, Int32, Ptr{Cdouble}, Ptr{Cdouble}, Int32, Ptr{Cdouble}),
+                eng.h, length(capacity), capacity, for_rate, length(hourly_load), hourly_load), eng.h, "relmc_hl1_load")
+    acc = Hl1Acc()
+    check(ccall((:relmc_hl1_nsq, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int64, Ref{Hl1Acc}, Ptr{Cdouble}, Ptr{Cdouble}),
+                eng.h, seed, 0, n_iterations, acc, C_NULL, C_NULL), eng.h, "relmc_hl1_nsq")
+    return (lole_hours_yr=acc.sum_lole / acc.n, eue_mwh_yr=acc.sum_eue / acc.n)
+end
+
 end # module
