@@ -109,6 +109,8 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
     if (rc) return rc;
     a.partial = ctx->dpartial;
     a.scen_doubles = ctx->scen_doubles;
+    // the grid fills the device: first-dispatched and later wavefronts share every SIMD (see the kernel's priority balancing)
+    a.prio_mode = blocks != ctx->num_cu * ctx->blocks_per_cu ? 0u : (ctx->blocks_per_cu == 2 ? 1u : (ctx->blocks_per_cu == 1 && TL::WPB == 8 ? 2u : 0u));
     a.stash_off = ctx->stash_off;
 #if defined(RELMC_PHASE_TIMING) || defined(RELMC_TRACE)
     if (!ctx->dtiming) HIP_TRY(ctx, hipMalloc(&ctx->dtiming, sizeof(unsigned long long) * 8 * 65536));

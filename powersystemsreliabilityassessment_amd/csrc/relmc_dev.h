@@ -109,6 +109,7 @@ struct EvalArgs {
     int32_t* status;
     int32_t* iters;
     void* partial;                  // PartialT<tile>[gridDim.x * blockDim.x]
+    uint32_t prio_mode;             // issue-priority balancing between co-resident wavefronts: 0 off, 1 by grid half, 2 by wave half
     uint32_t scen_doubles;          // per-scenario LDS doubles (workspace + stash), = 2 mod 4
     uint32_t stash_off;             // start of the per-lane stash behind the workspace
     unsigned long long* timing;     // profiling builds: [waves][8] phase cycle counters (else null)

@@ -222,6 +222,14 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     const int64_t ngroups = (a.n + SPW - 1) / SPW;
     const int64_t gwave = (int64_t)blockIdx.x * WPB + (tid >> 6);
     const int64_t gstride = (int64_t)gridDim.x * WPB;
+    // Issue-priority balancing.  A SIMD hosts two of these wavefronts and arbitrates oldest-first, so the wavefronts that were
+    // dispatched first run ~20 % faster than the ones that joined them and the launch ends with half of the SIMD slots idle
+    // (measured: per-wave times 0.905 / 1.093 of the mean).  The first-dispatched half (a.prio_mode 1: first half of the grid
+    // when two workgroups share a CU; 2: first half of the waves of the workgroup) alternates between the lowest and the
+    // highest user priority on a clock bit, the other half stays in between: each wavefront wins the arbitration half of
+    // the TIME.  The work assignment stays static, so results are unchanged and reproducible.
+    const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? (tid >> 6) < WPB / 2 : false);
+    if (a.prio_mode != 0 && !prio_first) __builtin_amdgcn_s_setprio(1);
     for (int64_t grp = gwave; grp < ngroups; grp += gstride) {
         const int64_t sidx = grp * SPW + lane / RW;
         const bool live = sidx < a.n;
@@ -598,6 +606,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         PT_MARK(0)
         // ===== mips main loop =======================================
         while (__any(iterating)) {
+            if (prio_first) { if ((__builtin_readcyclecounter() >> 15) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             RELOAD_FENCE();
             if (iterating) {
                 // ---- evaluate h, Lx, barrier terms; scatter to LDS; convergence norms -------------
