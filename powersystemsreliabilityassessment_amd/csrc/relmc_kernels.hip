@@ -768,13 +768,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     conv = conv && mx_gh < A_(0, feastol) * (1.0 + vmax(mx_x, mx_z)) && mx_lx < A_(1, gradtol) * (1.0 + mx_lammu);
                 }
 #ifdef RELMC_ABLATE_FIXIT
-                if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }
-                else if (false) {}
+                if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }     // profiling only: fixed trip count, no other exit
+                (void)conv; (void)xnan;
 #else
                 if (conv) { status = 0; iterating = false; }
-#endif
                 else if (it > 0 && (xnan || alphap < A_(7, alpha_min) || alphad < A_(7, alpha_min) || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
+#endif
             }
             PT_MARK(3)
             RELOAD_FENCE();
@@ -904,7 +904,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     SLOT_FENCE();
                 }
                 step2 = row_sum<RW>(step2);
+#ifdef RELMC_ABLATE_FIXIT
+                if (false) {
+#else
                 if (!(step2 <= A_(8, max_stepsize) * A_(8, max_stepsize))) {
+#endif
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
