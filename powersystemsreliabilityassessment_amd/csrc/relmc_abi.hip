@@ -380,7 +380,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     ctx->scen_doubles = scen;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
-    ctx->lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double);   // 128: solver options
+    ctx->lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? 1024u * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));

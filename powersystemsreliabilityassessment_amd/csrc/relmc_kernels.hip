@@ -230,9 +230,65 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // the TIME.  The work assignment stays static, so results are unchanged and reproducible.
     const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? (tid >> 6) < WPB / 2 : false);
     if (a.prio_mode != 0 && !prio_first) __builtin_amdgcn_s_setprio(1);
-    for (int64_t grp = gwave; grp < ngroups; grp += gstride) {
+    // Fused non-sequential path on the 16-lane tile: every wavefront owns a contiguous range of scenario groups and walks
+    // it in windows of 64 scenarios.  The window's states are sampled up front, one scenario per lane, and ordered so that
+    // the states whose unit outages leave less capacity than the load (13-16 interior-point iterations instead of 12) share rows of the same groups: a
+    // wavefront iterates until the slowest of its four rows has converged (mean of the maximum 12.9 vs mean 12.19).
+    constexpr bool WINDOWED = (MODE == 0 && RW == 16);
+    uint32_t* const WIN = reinterpret_cast<uint32_t*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) +
+                          (size_t)SPW * WPB * a.scen_doubles * 2 + (size_t)(tid >> 6) * 256;      // [64 slots][4 words] per wavefront
+    int64_t wb_begin = gwave, wb_end = ngroups, wb_step = gstride;
+    if (WINDOWED) {
+        wb_begin = ngroups * gwave / gstride; wb_end = ngroups * (gwave + 1) / gstride; wb_step = 16;
+    }
+    for (int64_t wb = wb_begin; wb < wb_end; wb += wb_step) {
+    int win_groups = 1;
+    uint32_t win_valid = 0;
+    if (WINDOWED) {
+        const int64_t si = wb * 4 + lane;                          // this lane's scenario of the window
+        const bool valid = (wb + (lane >> 2)) < wb_end && si < a.n;
+        uint32_t m0 = 0, m1 = 0, m2 = 0, m3 = 0;
+        bool hard = false;
+        if (valid) {
+            const uint64_t gi = a.first_index + (uint64_t)si;
+            const int nblk = (ncomp + 3) >> 2;
+            for (int blk = 0; blk < nblk; ++blk) {
+                uint32_t w[4], nib = 0;
+                philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)a.seed, (uint32_t)(a.seed >> 32), w);
+#pragma unroll
+                for (int e = 0; e < 4; ++e) {
+                    const int k = blk * 4 + e;
+                    if (k < ncomp && w[e] < C.thr[k]) nib |= 1u << e;   // strict '<', mc_sampling.m:35
+                }
+                const uint32_t sh = nib << ((blk & 7) * 4);
+                const int wsel = blk >> 3;
+                if (wsel == 0) m0 |= sh; else if (wsel == 1) m1 |= sh; else if (wsel == 2) m2 |= sh; else m3 |= sh;
+            }
+            // ordering key only (never a result): the unit outages leave less capacity than the load.  Measured on the
+            // fixture: such states take 13-16 iterations, all others (line outages included) 12.
+            double cap = 0.0;
+            for (int k = 0; k < ng; ++k) {
+                const uint32_t wsel = k < 64 ? (k < 32 ? m0 : m1) : (k < 96 ? m2 : m3);
+                if (!((wsel >> (k & 31)) & 1u)) cap += C.i_hi[k];
+            }
+            hard = cap * base < C.total_load;
+        }
+        const uint64_t bv = __ballot(valid), bh = __ballot(valid && hard);
+        const uint64_t below = (1ull << lane) - 1ull;
+        const uint32_t n_valid = (uint32_t)__popcll(bv), n_easy = (uint32_t)__popcll(bv & ~bh);
+        if (valid) {
+            const uint32_t slot = hard ? n_easy + (uint32_t)__popcll(bh & below) : (uint32_t)__popcll(bv & ~bh & below);
+            uint4 pk; pk.x = m0; pk.y = m1; pk.z = m2; pk.w = m3;
+            *reinterpret_cast<uint4*>(WIN + 4 * slot) = pk;
+        }
+        RELOAD_FENCE();
+        win_valid = n_valid;
+        win_groups = (int)((n_valid + 3u) >> 2);
+    }
+    for (int wg = 0; wg < win_groups; ++wg) {
+        const int64_t grp = WINDOWED ? wb + wg : wb;
         const int64_t sidx = grp * SPW + lane / RW;
-        const bool live = sidx < a.n;
+        const bool live = WINDOWED ? (uint32_t)(wg * 4 + lane / RW) < win_valid : sidx < a.n;
         double lscale = 1.0;                 // load_scale_factor of seq_mcsimulation.m:38-42 (1 in the non-sequential path)
         uint32_t wgt = 1;                    // multiplicity of the state (MODE 3)
         int seq_year = 0, seq_hour = 0;
@@ -291,7 +347,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             } else {
                 if (rlane < OW) OB[rlane] = 0u;
                 RELOAD_FENCE();
-                if (MODE == 0) {
+                if (WINDOWED) {
+                    if (rlane < OW) OB[rlane] = WIN[4 * (wg * 4 + lane / RW) + rlane];
+                } else if (MODE == 0) {
                     const uint64_t gi = a.first_index + (uint64_t)sidx;
 #pragma unroll
                     for (int h = 0; h < (TL::NCOMPMAX / 4 + RW - 1) / RW; ++h) {
@@ -1019,6 +1077,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             }
         }
         PT_MARK(7)
+    }
     }
     PT_FLUSH
 }
