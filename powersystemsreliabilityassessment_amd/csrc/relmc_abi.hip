@@ -324,6 +324,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
             C.b_line[bus][C.b_nline[bus]++] = (uint8_t)(l | (side ? 0x80 : 0));
         }
     }
+    for (int i = 0; i < nb; ++i) { double s_ = 0.0; for (int e = 0; e < C.b_nline[i]; ++e) s_ += C.l_b[C.b_line[i][e] & 0x7f]; C.b_bsum[i] = s_; }   // same order as the kernel's loop
     int maxdeg = 0, maxinj_ = 0;
     for (int i = 0; i < nb; ++i) {
         uint64_t pk = 0;

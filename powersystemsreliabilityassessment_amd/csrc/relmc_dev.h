@@ -59,6 +59,7 @@ struct DevCaseT {
     uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), 0x7f = none
     uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0xff = none
     // lines
+    double b_bsum[NBT];             // sum of the susceptances of the bus' lines, in list order (all lines in service)
     double l_b[NLT];
     double l_rate[NLT];             // p.u. (0 = unlimited)
     uint32_t l_info[NLT];

@@ -409,7 +409,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int t = 0; t < BS; ++t) {
                     const int i = RW * t + rlane;
                     uint32_t adj = 0;
-                    if (i < nb) {
+                    if (i < nb && any_lout) {           // without a line outage no bus is isolated and the sweeps below are skipped
                         const int nlb = C.b_nline[i];
                         for (int e = 0; e < nlb; ++e) {
                             const uint32_t ent = C.b_line[i][e];
@@ -507,10 +507,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int t = 0; t < BS; ++t) {
                     const int i = RW * t + rlane;
                     if (i < nb) {
-                        bool anyon = false;
-                        const int nlb = C.b_nline[i];
-                        for (int e = 0; e < nlb; ++e) if (!outbit(OB, ng + (C.b_line[i][e] & 0x7f))) anyon = true;
-                        iso = iso || !anyon;
+                        if (any_lout) {
+                            bool anyon = false;
+                            const int nlb = C.b_nline[i];
+                            for (int e = 0; e < nlb; ++e) if (!outbit(OB, ng + (C.b_line[i][e] & 0x7f))) anyon = true;
+                            iso = iso || !anyon;
+                        }
                         LB[i] = any_lout ? i : nb - 1;
                         BF[i] = 0;
                     }
@@ -611,11 +613,14 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             for (int t = 0; t < BS; ++t) {
                 const int i = RW * t + rlane;
                 if (i < nb) {
-                    double d = 0.0;
-                    const int nlb = C.b_nline[i];
-                    for (int e = 0; e < nlb; ++e) {
-                        const int l = C.b_line[i][e] & 0x7f;
-                        if (!outbit(OB, ng + l)) d += C.l_b[l];
+                    double d = C.b_bsum[i];             // every line in service: the host's sum in the same order
+                    if (any_lout) {
+                        d = 0.0;
+                        const int nlb = C.b_nline[i];
+                        for (int e = 0; e < nlb; ++e) {
+                            const int l = C.b_line[i][e] & 0x7f;
+                            if (!outbit(OB, ng + l)) d += C.l_b[l];
+                        }
                     }
                     cBd[t] = (B_PIN(t) || B_DROP(t)) ? 0.0 : d;
                 }
