@@ -4,7 +4,7 @@ SURVEY.md §8e: the reference's only parallelism is the `parfor` over sampled st
 (nsqMain.m:257-263); scenarios are i.i.d., so every super-batch [done, done+batch) of the global
 scenario index range is split contiguously across the ranks, each rank runs the fused
 sample -> evaluate -> reduce kernel on its slice, and the additive accumulators (relmc_acc,
-~390 words) are summed with ONE all-reduce (RCCL over xGMI when the process group is "nccl").
+~390 words, counters carried as exact fp64) are summed with ONE all-reduce (RCCL over xGMI when the process group is "nccl").
 Because the sampler is keyed by (seed, global index), the merged accumulators do not depend on
 the number of ranks (integers exactly, fp64 sums up to summation order).
 """
@@ -29,14 +29,19 @@ def allreduce_acc(acc: _abi.Acc, device=None) -> _abi.Acc:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return acc
     ints, dbls = acc.to_arrays()
-    ti = torch.from_numpy(ints)
-    td = torch.from_numpy(dbls)
-    if dist.get_backend() == "nccl":
-        dev = device if device is not None else torch.device("cuda", torch.cuda.current_device())
-        ti, td = ti.to(dev), td.to(dev)
-    dist.all_reduce(ti, op=dist.ReduceOp.SUM)
-    dist.all_reduce(td, op=dist.ReduceOp.SUM)
-    return _abi.Acc.from_arrays(ti.cpu().numpy(), td.cpu().numpy())
+    world = dist.get_world_size()
+    on_gpu = dist.get_backend() == "nccl"
+    dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else None
+    # ONE collective: the int64 counters ride along as fp64, exact below 2^53 also after the sum over the ranks (a launch
+    # counts at most 2^31 scenarios x ~20 iterations; the branch-free form keeps every rank in the same collective)
+    if int(np.abs(ints).max(initial=0)) >= (1 << 52) // max(world, 1):
+        raise OverflowError("relmc_acc counter too large to all-reduce as fp64; reduce per launch, not the running total")
+    buf = torch.from_numpy(np.concatenate([ints.astype(np.float64), dbls]))
+    if on_gpu:
+        buf = buf.to(dev)
+    dist.all_reduce(buf, op=dist.ReduceOp.SUM)
+    out = buf.cpu().numpy()
+    return _abi.Acc.from_arrays(np.rint(out[:ints.size]).astype(np.int64), out[ints.size:])
 
 
 def merge(a: _abi.Acc, b: _abi.Acc) -> _abi.Acc:
