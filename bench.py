@@ -272,7 +272,11 @@ def cpu_baseline(case, policy, seed, n_sample):
     t0 = time.perf_counter()
     acc = orc.nsq_accumulate(seed, 0, n, policy, nthreads=cores, memo=False)
     dt = time.perf_counter() - t0
-    return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port",
+    t1 = time.perf_counter()
+    n1 = 1500
+    orc.nsq_accumulate(seed, 0, n1, policy, nthreads=1, memo=False)                  # single-core figure as well
+    dt1 = time.perf_counter() - t1
+    return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port", "single_core_value": n1 / dt1,
             "sample": f"first {n} scenarios of the same seed, every scenario solved (no state memo), "
                       f"{dt:.1f} s on {cores} OpenMP threads",
             "edns_mw": acc.sum_dns / acc.n}
