@@ -264,7 +264,15 @@ def cpu_baseline(case, policy, seed, n_sample):
     only — never the thing measured as `value`."""
     from oracle import coracle
     orc = coracle.Oracle(case)
-    cores = orc.max_threads()
+    cores = min(orc.max_threads(), len(os.sched_getaffinity(0)))
+    quota = None
+    try:                                       # container CPU quota (cgroup v2): the box shows 256 CPUs but grants fewer
+        q, per = open("/sys/fs/cgroup/cpu.max").read().split()
+        if q != "max":
+            quota = max(1, int(round(int(q) / int(per))))
+            cores = min(cores, quota)
+    except (OSError, ValueError):
+        pass
     t0 = time.perf_counter()
     orc.nsq_accumulate(seed, 0, 200 * cores, policy, nthreads=cores, memo=False)     # calibration
     rate = 200 * cores / (time.perf_counter() - t0)
@@ -276,9 +284,9 @@ def cpu_baseline(case, policy, seed, n_sample):
     n1 = 1500
     orc.nsq_accumulate(seed, 0, n1, policy, nthreads=1, memo=False)                  # single-core figure as well
     dt1 = time.perf_counter() - t1
-    return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port", "single_core_value": n1 / dt1,
+    return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port", "single_core_value": n1 / dt1, "cpu_quota": quota,
             "sample": f"first {n} scenarios of the same seed, every scenario solved (no state memo), "
-                      f"{dt:.1f} s on {cores} OpenMP threads",
+                      f"{dt:.1f} s on {cores} OpenMP threads (host CPUs visible {os.cpu_count()}, cgroup quota {quota})",
             "edns_mw": acc.sum_dns / acc.n}
 
 
