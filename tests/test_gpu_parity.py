@@ -220,3 +220,14 @@ def test_full_size_properties_1e6(engine):
     assert whole.n == n and whole.n_fail == int((dns > 1e-4).sum())
     assert whole.sum_dns == pytest.approx(dns.sum(), rel=1e-11)
     np.testing.assert_array_equal(np.array(whole.comp_fail[:case.ncomp]), st[dns > 1e-4].sum(0))
+
+
+def test_fused_path_ragged_ranges(engine, oracle):
+    """Ranges that do not fill a sampling window, a group or a wavefront: integer accumulators equal the oracle's."""
+    for n in (1, 3, 4, 5, 63, 64, 65, 255, 1000):
+        acc = engine.nsq_accumulate(21, 777, n)
+        ref = oracle.nsq_accumulate(21, 777, n, api.REFERENCE_EMULATE)
+        ai, ad = acc.to_arrays(); ri, rd = ref.to_arrays()
+        assert np.array_equal(ai[:5], ri[:5]) and np.array_equal(ai[6:], ri[6:]), n
+        np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8, atol=1e-9)
+    assert engine.nsq_accumulate(21, 777, 0).n == 0
