@@ -12,6 +12,9 @@ CSRC = os.path.join(ROOT, "powersystemsreliabilityassessment_amd", "csrc")
 
 
 def _build_client(tmp_path):
+    from powersystemsreliabilityassessment_amd import _lib
+    if not os.path.exists(_lib.LIB_PATH):
+        _lib.build()                              # hipcc cross-compiles without a GPU
     exe = str(tmp_path / "abi_smoke")
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", INC, os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
                            "-o", exe, "-L", CSRC, "-lrelmc", "-Wl,-rpath," + CSRC])
