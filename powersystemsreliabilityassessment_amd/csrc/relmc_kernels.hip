@@ -856,10 +856,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const double* Wa = W + (dsc.x >> 16);
                         const double* Wb = W + (dsc.y & 0xffffu);
                         const double* D = W + (dsc.y >> 16);
-                        const d2 dA = ld2(D), dB = ld2(D + 2);
+                        const d2 dA = ld2(D); const double dBy = D[3];      // D = [[m, b], [b, -e]]: the second half is needed for -e only (b64 read)
                         const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
                         d2 t0 = ld2(T);
-                        const double pm = dA.x, pb = dA.y, pe = -dB.y;
+                        const double pm = dA.x, pb = dA.y, pe = -dBy;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
                         const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
@@ -881,8 +881,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         double* D = W + (dsc.x & 0xffffu);
                         double* Y = W + (dsc.x >> 16);
-                        const d2 dA = ld2(D), dB = ld2(D + 2), y = ld2(Y);
-                        const double pm = dA.x, pb = dA.y, pe = -dB.y;
+                        const d2 dA = ld2(D), y = ld2(Y); const double dBy = D[3];
+                        const double pm = dA.x, pb = dA.y, pe = -dBy;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
                         st2(D, P00, P01); st2(D + 2, P01, P11);
