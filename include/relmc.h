@@ -137,18 +137,24 @@ typedef struct {
     double* edns_history;
     double* lole_history;
     double* plc_history;
-    int32_t distinct_states;  /* 1: evaluate every distinct state of a batch once and count multiplicities, the
-                                 reference's unique-state database (nsqMain.m:220-245) per batch; 0 (default): solve
-                                 every sample.  The estimators are identical. */
+    int32_t distinct_states;  /* 0 (default): solve every sample.
+                                 1: evaluate every distinct state of a batch once and count multiplicities (the
+                                    reference's dedupe, nsqMain.m:220-229, per batch).
+                                 2: the reference's persistent unique-state database (nsqMain.m:91-99, 220-278): states
+                                    seen in an earlier batch only bump their count, only new states are solved, and the
+                                    indices are recomputed from all rows after every batch (:282-301).  The run starts
+                                    from an empty database (relmc_db_reset).
+                                 The estimators are identical in all three. */
 } relmc_nsq_opts;
 
 typedef struct {
     relmc_acc acc;
     relmc_indices idx;
-    int64_t checkpoints;      /* history entries written */
+    int64_t checkpoints;      /* history entries written = min(batches, history_cap) */
     int32_t converged;        /* beta <= beta_limit */
     double wall_seconds;      /* host wall time of the loop */
     double kernel_seconds;    /* HIP-event time of the fused kernels */
+    int64_t batches;          /* convergence checks made (passes of the nsqMain.m:208 loop) */
 } relmc_nsq_result;
 
 /* ---- lifetime ---------------------------------------------------------------------- */
@@ -192,6 +198,34 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
 int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
                                       const relmc_solver_opts* opts, relmc_acc* acc_out, int64_t* n_distinct_out);
 int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
+
+/* ---- persistent unique-state database (nsqMain.m:91-99, 220-278) ------------------------- */
+/* The reference keeps every distinct state it has ever sampled in `state_database` (columns: Ng+Nl component states |
+ * count | dns | failure flag | Nb nodal values, nsqMain.m:91-99).  Per batch it removes duplicates (:220-229), bumps the
+ * counts of states already in the database (:232-245), evaluates only the new ones (:257-263), appends them (:269-278)
+ * and recomputes the indices from all rows (:282-301).  The same on the device: rows in HBM, an open-addressing table of
+ * row ids, new rows appended in the order of first appearance in the sample stream (unique(...,'stable')), so the
+ * database and every sum over it depend on (seed, samples drawn) only, not on the batch size.
+ *   relmc_db_reset       empty database (relmc_case_load does the same)
+ *   relmc_nsq_db_batch   one pass of the loop body over samples [first_index, first_index + n); acc_out (optional) =
+ *                        accumulators of the WHOLE database afterwards (cumulative, not the batch's increment)
+ *   relmc_db_accumulate  the accumulators of the whole database again (no sampling)
+ *   relmc_db_size        rows and samples held
+ *   relmc_db_export      rows [first_row, first_row + n_rows) in the reference's column layout; any output may be NULL:
+ *                        states[n x (ng+nl)], count[n], dns[n], flag[n] (dns > 1e-4, :270), nodal[n x nb], status[n], iters[n] */
+typedef struct {
+    int64_t rows;             /* distinct states in the database (database_row_count)     */
+    int64_t samples;          /* samples they stand for (sum of the count column)          */
+    int64_t new_rows;         /* states evaluated by this call (num_new_states, :255)       */
+    int64_t batch_distinct;   /* distinct states of this call's samples before the lookup   */
+} relmc_db_stats;
+int32_t relmc_db_reset(relmc_ctx* ctx);
+int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
+                           const relmc_solver_opts* opts, relmc_acc* acc_out, relmc_db_stats* stats_out);
+int32_t relmc_db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out);
+int32_t relmc_db_size(const relmc_ctx* ctx, int64_t* rows_out, int64_t* samples_out);
+int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8_t* states_host, int64_t* count_host,
+                        double* dns_host, int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host);
 
 /* ---- estimators (host arithmetic, no device) ---------------------------------------- */
 void relmc_acc_zero(relmc_acc* acc);

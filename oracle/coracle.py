@@ -42,6 +42,11 @@ def lib():
                                          C.POINTER(_abi.SolverOpts), C.c_int32, C.c_int32,
                                          C.POINTER(_abi.Acc)]
         L.orc_nsq_accumulate.restype = C.c_int32
+        i64p = _abi.c_int64_p
+        L.orc_nsq_database.argtypes = [C.POINTER(_abi.CaseDesc), C.c_uint64, C.c_double, C.c_int64, C.c_int64, C.POINTER(_abi.SolverOpts),
+                                       C.c_int32, C.c_int64, u8p, i64p, dp, i32p, dp, i32p, i32p, i32p, i64p,
+                                       C.c_int64, dp, dp, dp, dp, i64p, i64p, C.POINTER(_abi.Acc)]
+        L.orc_nsq_database.restype = C.c_int32
         L.orc_nsq_indices.argtypes = [C.POINTER(_abi.Acc), C.c_int32, C.c_int32, C.c_double,
                                       C.POINTER(_abi.Indices)]
         L.orc_nsq_indices.restype = None
@@ -106,6 +111,34 @@ class Oracle:
                                        1 if memo else 0, C.byref(acc))
         assert rc == 0
         return acc
+
+    def nsq_database(self, seed, beta_limit=0.0017, max_iterations=100000, samples_per_batch=100,
+                     policy=_abi.RELMC_REFERENCE_EMULATE, opts=None, nthreads=None, max_rows=None):
+        """nsqMain.m:208-308 in the reference's own database form.  Returns dict(states, count, dns, flag, nodal, status,
+        iters, relaxed, beta_history, edns_history, lole_history, plc_history, iterations, acc)."""
+        o = opts or _abi.default_solver_opts(policy)
+        cap = int(max_rows or max_iterations)
+        nc, nb = self.case.ncomp, self.case.nb
+        ncp = (int(max_iterations) + int(samples_per_batch) - 1) // int(samples_per_batch)
+        d = dict(states=np.zeros((cap, nc), dtype=np.uint8), count=np.zeros(cap, dtype=np.int64), dns=np.zeros(cap),
+                 flag=np.zeros(cap, dtype=np.int32), nodal=np.zeros((cap, nb)), status=np.zeros(cap, dtype=np.int32),
+                 iters=np.zeros(cap, dtype=np.int32), relaxed=np.zeros(cap, dtype=np.int32))
+        h = [np.zeros(ncp) for _ in range(4)]
+        rows, cp, its = C.c_int64(), C.c_int64(), C.c_int64()
+        acc = _abi.Acc()
+        p = lambda a, t: a.ctypes.data_as(t)
+        rc = self.L.orc_nsq_database(C.byref(self.h.desc), seed, beta_limit, max_iterations, samples_per_batch, C.byref(o),
+                                     nthreads or self.L.orc_max_threads(), cap, p(d["states"], _abi.c_uint8_p), p(d["count"], _abi.c_int64_p),
+                                     p(d["dns"], _abi.c_double_p), p(d["flag"], _abi.c_int32_p), p(d["nodal"], _abi.c_double_p),
+                                     p(d["status"], _abi.c_int32_p), p(d["iters"], _abi.c_int32_p), p(d["relaxed"], _abi.c_int32_p),
+                                     C.byref(rows), ncp, p(h[0], _abi.c_double_p), p(h[1], _abi.c_double_p), p(h[2], _abi.c_double_p),
+                                     p(h[3], _abi.c_double_p), C.byref(cp), C.byref(its), C.byref(acc))
+        assert rc == 0, rc
+        n, k = int(rows.value), int(cp.value)
+        out = {key: v[:n] for key, v in d.items()}
+        out.update(beta_history=h[0][:k], edns_history=h[1][:k], lole_history=h[2][:k], plc_history=h[3][:k],
+                   iterations=int(its.value), acc=acc)
+        return out
 
     def indices(self, acc, hours=8760.0):
         out = _abi.Indices()

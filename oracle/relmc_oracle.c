@@ -22,6 +22,7 @@
  *   mc_simulation.m:54-59    -> dns = f + load, dns < 0.1 -> 0
  *   mc_simulation.m:62-99    -> nodal shed of the virtual generators, > 1e-3
  *   nsqMain.m:270,282-301    -> accumulators (fail flag dns > 1e-4)
+ *   nsqMain.m:208-308        -> orc_nsq_database (the loop in its own unique-state database form)
  */
 #include "relmc_oracle.h"
 
@@ -699,6 +700,138 @@ int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t fir
     for (int t = 0; t < nthreads; ++t) acc_merge(acc_out, &part[t]);
     free(part);
     return RELMC_OK;
+}
+
+/* ---- nsqMain.m:208-308 restated literally in DATABASE form (the checker of the device state database) -----------
+ * Per batch: mc_sampling (:212); unique(rows,'stable') with counts (:220-229); intersect with the database -> bump the
+ * counts of known states, drop them (:232-245); evaluate the new states (parfor, :257-263); append [state, count, dns,
+ * flag, nodal] (:269-278); indices from ALL rows (:282-301, beta with the central sum as written there); histories
+ * (:304-308).  Loop condition of :208.  Rows come out in the order the reference would hold them. */
+typedef struct { uint64_t k[4]; int64_t row; int used; } dbmap_ent;
+typedef struct { dbmap_ent* e; size_t cap, n; } dbmap_t;
+static dbmap_ent* dbmap_find(dbmap_t* m, const uint64_t k[4])
+{
+    if (m->n * 2 >= m->cap) {
+        size_t ncap = m->cap ? m->cap * 2 : 1024;
+        dbmap_ent* ne = (dbmap_ent*)xm(sizeof(dbmap_ent) * ncap);
+        for (size_t i = 0; i < m->cap; ++i) if (m->e[i].used) {
+            size_t p = mix64(m->e[i].k[0] ^ mix64(m->e[i].k[1] ^ mix64(m->e[i].k[2] ^ mix64(m->e[i].k[3])))) & (ncap - 1);
+            while (ne[p].used) p = (p + 1) & (ncap - 1);
+            ne[p] = m->e[i];
+        }
+        free(m->e); m->e = ne; m->cap = ncap;
+    }
+    size_t p = mix64(k[0] ^ mix64(k[1] ^ mix64(k[2] ^ mix64(k[3])))) & (m->cap - 1);
+    while (m->e[p].used) {
+        if (m->e[p].k[0] == k[0] && m->e[p].k[1] == k[1] && m->e[p].k[2] == k[2] && m->e[p].k[3] == k[3]) return &m->e[p];
+        p = (p + 1) & (m->cap - 1);
+    }
+    memcpy(m->e[p].k, k, sizeof(uint64_t) * 4);
+    return &m->e[p];
+}
+
+int32_t orc_nsq_database(const relmc_case_desc* c, uint64_t seed, double beta_limit, int64_t max_iterations, int64_t samples_per_batch,
+                         const relmc_solver_opts* opts, int32_t nthreads, int64_t max_rows,
+                         uint8_t* db_states, int64_t* db_count, double* db_dns, int32_t* db_flag, double* db_nodal,
+                         int32_t* db_status, int32_t* db_iters, int32_t* db_relaxed, int64_t* rows_out,
+                         int64_t hist_cap, double* beta_hist, double* edns_hist, double* lole_hist, double* plc_hist,
+                         int64_t* checkpoints_out, int64_t* iterations_out, relmc_acc* acc_out)
+{
+    const int ncomp = c->ng + c->nl, nb = c->nb;
+    if (nb > RELMC_MAX_BUS || ncomp > RELMC_MAX_COMP || samples_per_batch < 1) return RELMC_ERR_UNSUPPORTED;
+    if (nthreads < 1) nthreads = 1;
+    uint32_t thr[RELMC_MAX_COMP];
+    orc_thresholds(c, thr);
+    dbmap_t dbm = {0, 0, 0};
+    int64_t rows = 0, current_iteration = 0, cp = 0;
+    double current_beta = INFINITY;
+    uint8_t* bst = (uint8_t*)xm((size_t)samples_per_batch * ncomp);          /* the batch's unique states, in order of appearance */
+    int64_t* bcnt = (int64_t*)xm(sizeof(int64_t) * samples_per_batch);
+    int64_t* newrow = (int64_t*)xm(sizeof(int64_t) * samples_per_batch);
+    orc_ws** ws = (orc_ws**)xm(sizeof(orc_ws*) * nthreads);
+    for (int t = 0; t < nthreads; ++t) ws[t] = ws_new(c);
+    int32_t rc = RELMC_OK;
+    while (current_beta > beta_limit && current_iteration < max_iterations) {          /* nsqMain.m:208 */
+        /* :212 + :220-229: sample, unique rows in order of first appearance, counts */
+        dbmap_t bm = {0, 0, 0};
+        int64_t nuniq = 0;
+        uint8_t st[RELMC_MAX_COMP];
+        for (int64_t i = 0; i < samples_per_batch; ++i) {
+            sample_state(thr, ncomp, seed, (uint64_t)(current_iteration + i), st);
+            uint64_t key[4] = {0, 0, 0, 0};
+            for (int k = 0; k < ncomp; ++k) if (st[k]) key[k >> 6] |= 1ULL << (k & 63);
+            dbmap_ent* e = dbmap_find(&bm, key);
+            if (!e->used) { e->used = 1; bm.n++; e->row = nuniq; memcpy(bst + (size_t)nuniq * ncomp, st, (size_t)ncomp); bcnt[nuniq] = 0; nuniq++; }
+            bcnt[e->row] += 1;
+        }
+        free(bm.e);
+        /* :232-245: states already in the database collect the batch's counts; the others are new */
+        int64_t nnew = 0;
+        for (int64_t u = 0; u < nuniq; ++u) {
+            const uint8_t* s_ = bst + (size_t)u * ncomp;
+            uint64_t key[4] = {0, 0, 0, 0};
+            for (int k = 0; k < ncomp; ++k) if (s_[k]) key[k >> 6] |= 1ULL << (k & 63);
+            dbmap_ent* e = dbmap_find(&dbm, key);
+            if (e->used) db_count[e->row] += bcnt[u];
+            else {
+                if (rows + nnew >= max_rows) { rc = RELMC_ERR_UNSUPPORTED; goto done; }
+                e->used = 1; dbm.n++; e->row = rows + nnew;
+                memcpy(db_states + (size_t)e->row * ncomp, s_, (size_t)ncomp);
+                db_count[e->row] = bcnt[u];
+                newrow[nnew++] = e->row;
+            }
+        }
+        /* :257-263 (parfor) + :269-278 */
+#pragma omp parallel for num_threads(nthreads) schedule(dynamic, 4)
+        for (int64_t q = 0; q < nnew; ++q) {
+#ifdef _OPENMP
+            orc_ws* w = ws[omp_get_thread_num()];
+#else
+            orc_ws* w = ws[0];
+#endif
+            const int64_t r = newrow[q];
+            solve_state(c, db_states + (size_t)r * ncomp, 1.0, opts, w, &db_dns[r], db_nodal + (size_t)r * nb, &db_status[r], &db_iters[r], &db_relaxed[r]);
+            db_flag[r] = db_dns[r] > 1e-4 ? 1 : 0;                                       /* :270 */
+        }
+        rows += nnew;
+        /* :282-301 */
+        const double current_samples = (double)(current_iteration + samples_per_batch);
+        double sdns = 0.0, sflag = 0.0;
+        for (int64_t r = 0; r < rows; ++r) { sdns += (double)db_count[r] * db_dns[r]; sflag += (double)db_count[r] * (double)db_flag[r]; }
+        const double edns = sdns / current_samples;
+        const double lole = sflag / current_samples * 8760.0;
+        const double plc = sflag / current_samples;
+        double ss = 0.0;
+        for (int64_t r = 0; r < rows; ++r) { const double d = db_dns[r] - edns; ss += (double)db_count[r] * d * d; }
+        current_beta = sqrt(ss) / current_samples / edns;
+        if (cp < hist_cap) { beta_hist[cp] = current_beta; edns_hist[cp] = edns; lole_hist[cp] = lole; plc_hist[cp] = plc; }   /* :304-308 */
+        cp++;
+        current_iteration += samples_per_batch;
+    }
+done:
+    /* the additive accumulators of include/relmc.h from the database rows (what the device path all-reduces) */
+    if (acc_out) {
+        memset(acc_out, 0, sizeof(*acc_out));
+        for (int64_t r = 0; r < rows; ++r) {
+            const int64_t cn = db_count[r];
+            acc_out->n += cn;
+            acc_out->sum_dns += (double)cn * db_dns[r];
+            acc_out->sum_dns2 += (double)cn * db_dns[r] * db_dns[r];
+            acc_out->sum_iters += cn * db_iters[r];
+            if (db_status[r] == RELMC_ST_SINGULAR) acc_out->n_singular += cn;
+            if (db_status[r] == RELMC_ST_MAXIT || db_status[r] == RELMC_ST_NUMFAIL) acc_out->n_nonconverged += cn;
+            if (db_relaxed[r]) acc_out->n_infeasible += cn;
+            for (int i = 0; i < nb; ++i) acc_out->sum_nodal[i] += (double)cn * db_nodal[(size_t)r * nb + i];
+            if (db_flag[r]) {
+                acc_out->n_fail += cn;
+                for (int k = 0; k < ncomp; ++k) acc_out->comp_fail[k] += cn * db_states[(size_t)r * ncomp + k];
+            }
+        }
+    }
+    *rows_out = rows; *checkpoints_out = cp; *iterations_out = current_iteration;
+    for (int t = 0; t < nthreads; ++t) ws_free(ws[t]);
+    free(ws); free(bst); free(bcnt); free(newrow); free(dbm.e);
+    return rc;
 }
 
 /* estimators, nsqMain.m:282-301, 348-349, 366-376 (independent restatement of relmc_nsq_indices) */

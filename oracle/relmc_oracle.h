@@ -18,6 +18,12 @@ int32_t orc_mc_simulation(const relmc_case_desc* c, const uint8_t* states, int64
 int32_t orc_nsq_accumulate(const relmc_case_desc* c, uint64_t seed, uint64_t first_index, int64_t n,
                            const relmc_solver_opts* opts, int32_t nthreads, int32_t use_memo,
                            relmc_acc* acc_out);
+int32_t orc_nsq_database(const relmc_case_desc* c, uint64_t seed, double beta_limit, int64_t max_iterations, int64_t samples_per_batch,
+                         const relmc_solver_opts* opts, int32_t nthreads, int64_t max_rows,
+                         uint8_t* db_states, int64_t* db_count, double* db_dns, int32_t* db_flag, double* db_nodal,
+                         int32_t* db_status, int32_t* db_iters, int32_t* db_relaxed, int64_t* rows_out,
+                         int64_t hist_cap, double* beta_hist, double* edns_hist, double* lole_hist, double* plc_hist,
+                         int64_t* checkpoints_out, int64_t* iterations_out, relmc_acc* acc_out);
 void orc_nsq_indices(const relmc_acc* a, int32_t nb, int32_t ncomp, double hours, relmc_indices* out);
 int32_t orc_seq_mcsimulation(const relmc_case_desc* c, const uint8_t* states, const double* load_scale, int64_t n,
                              const relmc_solver_opts* opts, double* dns, double* nodal,

@@ -21,6 +21,7 @@ c_double_p = C.POINTER(C.c_double)
 c_int32_p = C.POINTER(C.c_int32)
 c_uint8_p = C.POINTER(C.c_uint8)
 c_uint32_p = C.POINTER(C.c_uint32)
+c_int64_p = C.POINTER(C.c_int64)
 
 
 class CaseDesc(C.Structure):
@@ -102,7 +103,12 @@ class NsqResult(C.Structure):
         ("acc", Acc), ("idx", Indices),
         ("checkpoints", C.c_int64), ("converged", C.c_int32),
         ("wall_seconds", C.c_double), ("kernel_seconds", C.c_double),
+        ("batches", C.c_int64),
     ]
+
+
+class DbStats(C.Structure):
+    _fields_ = [("rows", C.c_int64), ("samples", C.c_int64), ("new_rows", C.c_int64), ("batch_distinct", C.c_int64)]
 
 
 assert C.sizeof(Acc) == (Acc.N_INT + Acc.N_DBL) * 8

@@ -23,6 +23,7 @@ EXPORTS = [
     "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate", "relmc_nsq_accumulate_distinct",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
+    "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years",
 ]
 
@@ -100,6 +101,17 @@ def load():
     L.relmc_nsq_indices.restype = None
     L.relmc_nsq_run.argtypes = [vp, C.POINTER(_abi.NsqOpts), C.POINTER(_abi.NsqResult)]
     L.relmc_nsq_run.restype = C.c_int32
+    L.relmc_db_reset.argtypes = [vp]
+    L.relmc_db_reset.restype = C.c_int32
+    L.relmc_nsq_db_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts), C.POINTER(_abi.Acc),
+                                     C.POINTER(_abi.DbStats)]
+    L.relmc_nsq_db_batch.restype = C.c_int32
+    L.relmc_db_accumulate.argtypes = [vp, C.POINTER(_abi.Acc)]
+    L.relmc_db_accumulate.restype = C.c_int32
+    L.relmc_db_size.argtypes = [vp, _abi.c_int64_p, _abi.c_int64_p]
+    L.relmc_db_size.restype = C.c_int32
+    L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p]
+    L.relmc_db_export.restype = C.c_int32
     if hasattr(L, "relmc_dpp_probe"):
         L.relmc_dpp_probe.argtypes = [vp, dp, dp]
         L.relmc_dpp_probe.restype = C.c_int32

@@ -64,6 +64,59 @@ class NsqResult:
     elapsed_time: float
     kernel_seconds: float
     acc: _abi.Acc = field(repr=False, default=None)
+    samples_per_batch: int = 100
+    beta_limit: float = 0.0017
+    database_row_count: int | None = None      # unique states evaluated (only the database path keeps them)
+    hours_per_year: float = 8760.0
+
+    # -- what nsqMain prints (nsqMain.m:314-317, 325-393) ---------------------------------------------------------
+    def progress_lines(self, every: int = 1000) -> list[str]:
+        """The loop's progress print (nsqMain.m:314-317): one line whenever the sample count is a multiple of `every`."""
+        out = []
+        for k in range(len(self.beta_history)):
+            it = (k + 1) * self.samples_per_batch
+            if it > self.current_iteration:
+                it = self.current_iteration
+            if it % every == 0:
+                out.append("Iteration %6d: Beta = %.6f, EDNS = %.4f MW, LOLE = %.4f hr/yr"
+                           % (it, self.beta_history[k], self.edns_history[k], self.lole_history[k]))
+        return out
+
+    def top_buses(self, k: int = 5):
+        """[(bus number 1-based, EENS MWh/yr)] of the k worst buses, nsqMain.m:351-358 (zero entries are not listed)."""
+        order = np.argsort(-self.nodal_eens, kind="stable")[:k]
+        return [(int(i) + 1, float(self.nodal_eens[i]) * self.hours_per_year) for i in order if self.nodal_eens[i] > 0]
+
+    def top_components(self, k: int = 5, numGenerators: int | None = None):
+        """[(type, id 1-based, P(down | system failure))] of the k most critical components, nsqMain.m:378-389."""
+        ng = numGenerators if numGenerators is not None else self._ng
+        order = np.argsort(-self.comp_importance, kind="stable")[:k]
+        return [(("Gen", int(c) + 1) if c < ng else ("Line", int(c) - ng + 1)) + (float(self.comp_importance[c]),) for c in order]
+
+    def report(self, progress_every: int = 1000) -> str:
+        """Text of nsqMain.m's console output from the Monte Carlo loop on (:314-317 progress, :325-393 results,
+        nodal indices and weak-point detection), same wording and number formats."""
+        L = list(self.progress_lines(progress_every))
+        L += ["", "========================================", "SECTION 8: SIMULATION RESULTS", "========================================",
+              "Total simulation time: %.2f seconds" % self.elapsed_time, "Total iterations: %d" % self.current_iteration]
+        if self.database_row_count is not None:
+            L.append("Unique states evaluated: %d" % self.database_row_count)
+        L += ["Convergence achieved: %s" % ("YES" if self.current_beta <= self.beta_limit else "NO"), "", "--- RELIABILITY INDICES ---",
+              "EDNS (Expected Demand Not Supplied): %.4f MW" % self.accumulated_edns,
+              "LOLE (Loss of Load Expectation): %.4f hours/year" % self.accumulated_lole,
+              "PLC (Probability of Load Curtailment): %.6f" % self.plc,
+              "Beta (Coefficient of Variation): %.6f" % self.current_beta, "", "--- NODAL RELIABILITY INDICES ---",
+              "Top 5 Buses by EENS (MWh/yr):"]
+        L += ["  Bus %2d: %.4f MWh/yr" % bv for bv in self.top_buses(5)]
+        L += ["", "--- WEAK POINT DETECTION ---"]
+        if self.acc is not None and self.acc.n_fail > 0:
+            L.append("Top 5 Critical Components (Prob. Down given System Failure):")
+            L += ["  %s %2d: %.2f%%" % (t, i, v * 100.0) for t, i, v in self.top_components(5)]
+        else:
+            L.append("No failure events recorded to analyze weak points.")
+        return "\n".join(L)
+
+    _ng: int = field(repr=False, default=33)
 
     def write_nodal_csv(self, path: str, hours_per_year: float = 8760.0) -> None:
         """nodal_results.csv exactly as nsqMain.m:398-400 writes it (BusID, EENS_MWh_yr)."""
@@ -137,8 +190,10 @@ class Engine:
             if fp.size != ng + nl:
                 raise ValueError("failure_probabilities must have numGenerators+numLines entries")
             if not np.array_equal(fp, self.case.unavail):
-                import dataclasses
-                self.load_case(dataclasses.replace(self.case, unavail=fp.copy()))
+                # the thresholds live in the device case: swapping them here would silently change every later
+                # nsq_accumulate / nsqMain call and drop a loaded sequential model
+                raise ValueError("failure_probabilities differ from the loaded case: call "
+                                 "Engine.load_case(dataclasses.replace(case, unavail=...)) explicitly")
         n = int(num_samples)
         out = np.zeros((n, ng + nl), dtype=np.uint8)
         self._check(self.L.relmc_mc_sampling(self._h, int(seed), int(first_index), n,
@@ -200,6 +255,40 @@ class Engine:
                                                          C.byref(nd)), "relmc_nsq_accumulate_distinct")
         return acc, int(nd.value)
 
+    # -- the reference's persistent unique-state database (nsqMain.m:91-99, 220-278) -----------------
+    def db_reset(self):
+        self._check(self.L.relmc_db_reset(self._h), "relmc_db_reset")
+
+    def nsq_db_batch(self, seed: int, first_index: int, n: int, mpopt=None):
+        """One pass of the reference's loop body over samples [first_index, first_index+n): dedupe, count bumps for known
+        states, evaluation of the new ones, indices from the whole database.  Returns (Acc of the whole database, DbStats)."""
+        o = mpopt if mpopt is not None else mpoption()
+        acc, st = _abi.Acc(), _abi.DbStats()
+        self._check(self.L.relmc_nsq_db_batch(self._h, int(seed), int(first_index), int(n), C.byref(o), C.byref(acc),
+                                              C.byref(st)), "relmc_nsq_db_batch")
+        return acc, st
+
+    def db_size(self):
+        rows, samples = C.c_int64(), C.c_int64()
+        self._check(self.L.relmc_db_size(self._h, C.byref(rows), C.byref(samples)), "relmc_db_size")
+        return int(rows.value), int(samples.value)
+
+    def db_export(self, first_row: int = 0, n_rows: int | None = None) -> dict:
+        """Rows of the database in the reference's column layout (nsqMain.m:91-99): states, count, dns, flag, nodal
+        (+ solver status and iteration count)."""
+        rows, _ = self.db_size()
+        n = rows - first_row if n_rows is None else int(n_rows)
+        nc, nb = self.case.ncomp, self.case.nb
+        out = dict(states=np.zeros((n, nc), dtype=np.uint8), count=np.zeros(n, dtype=np.int64), dns=np.zeros(n),
+                   flag=np.zeros(n, dtype=np.int32), nodal=np.zeros((n, nb)), status=np.zeros(n, dtype=np.int32),
+                   iters=np.zeros(n, dtype=np.int32))
+        self._check(self.L.relmc_db_export(self._h, int(first_row), n, out["states"].ctypes.data_as(_abi.c_uint8_p),
+                                           out["count"].ctypes.data_as(_abi.c_int64_p), out["dns"].ctypes.data_as(_abi.c_double_p),
+                                           out["flag"].ctypes.data_as(_abi.c_int32_p), out["nodal"].ctypes.data_as(_abi.c_double_p),
+                                           out["status"].ctypes.data_as(_abi.c_int32_p), out["iters"].ctypes.data_as(_abi.c_int32_p)),
+                    "relmc_db_export")
+        return out
+
     def last_kernel_ms(self) -> float:
         ms = C.c_double()
         self._check(self.L.relmc_last_kernel_ms(self._h, C.byref(ms)), "relmc_last_kernel_ms")
@@ -213,14 +302,18 @@ class Engine:
     # -- nsqMain.m:208-406 ---------------------------------------------------------------------
     def nsqMain(self, beta_limit: float = 0.0017, max_iterations: int = 100000,
                 samples_per_batch: int = 100, *, seed: int = 1, mpopt=None,
-                hours_per_year: float = 8760.0, distinct_states: bool = False) -> NsqResult:
+                hours_per_year: float = 8760.0, distinct_states: bool | int | str = False, verbose: bool = False) -> NsqResult:
         """Defaults are the reference's (nsqMain.m:60-62).  On a GPU a batch of 100 is tiny; pass
-        samples_per_batch >= 1e5 for throughput — the estimators do not depend on the batch size."""
+        samples_per_batch >= 1e5 for throughput — the estimators do not depend on the batch size.
+        distinct_states: False = every sample solved; True / 1 = distinct states of each batch solved once;
+        "database" / 2 = the reference's persistent unique-state database across batches (nsqMain.m:220-278).
+        verbose: print what the reference prints (progress every 1000 samples, results, top-5 buses / components)."""
         o = _abi.NsqOpts()
         self.L.relmc_nsq_opts_default(C.byref(o))
         o.beta_limit, o.max_samples, o.batch = float(beta_limit), int(max_iterations), int(samples_per_batch)
         o.seed, o.hours_per_year = int(seed), float(hours_per_year)
-        o.distinct_states = 1 if distinct_states else 0           # the reference's unique-state database, per batch
+        mode = 2 if distinct_states in ("database", 2) else (1 if distinct_states else 0)
+        o.distinct_states = mode
         if mpopt is not None:
             o.solver = mpopt
         ncp = (int(max_iterations) + int(samples_per_batch) - 1) // int(samples_per_batch)
@@ -232,14 +325,19 @@ class Engine:
         self._check(self.L.relmc_nsq_run(self._h, C.byref(o), C.byref(res)), "relmc_nsq_run")
         k = int(res.checkpoints)
         nb, nc = self.case.nb, self.case.ncomp
-        return NsqResult(
+        out = NsqResult(
             accumulated_edns=res.idx.edns, accumulated_lole=res.idx.lole, plc=res.idx.plc,
             current_beta=res.idx.beta, current_iteration=int(res.idx.n),
             nodal_eens=np.array(res.idx.nodal_eens[:nb]), comp_importance=np.array(res.idx.comp_importance[:nc]),
             beta_history=hist[0][:k], edns_history=hist[1][:k], lole_history=hist[2][:k], plc_history=hist[3][:k],
             converged=bool(res.converged), mean_iters=res.idx.mean_iters, n_singular=int(res.acc.n_singular),
             n_infeasible=int(res.acc.n_infeasible), n_nonconverged=int(res.acc.n_nonconverged),
-            elapsed_time=res.wall_seconds, kernel_seconds=res.kernel_seconds, acc=res.acc)
+            elapsed_time=res.wall_seconds, kernel_seconds=res.kernel_seconds, acc=res.acc,
+            samples_per_batch=int(samples_per_batch), beta_limit=float(beta_limit),
+            database_row_count=self.db_size()[0] if mode == 2 else None, hours_per_year=float(hours_per_year), _ng=self.case.ng)
+        if verbose:
+            print(out.report())
+        return out
 
 
 # ---- module-level functions with the reference's names (default engine on RTS-24) ---------------

@@ -44,6 +44,11 @@ struct relmc_ctx {
     int64_t memo_cap = 0; size_t memo_tmp_bytes = 0;
     uint32_t *mk = nullptr, *mperm0 = nullptr, *mperm1 = nullptr, *mhead = nullptr, *muid = nullptr, *mstart = nullptr, *mnu = nullptr;
     unsigned long long *mch0 = nullptr, *mch1 = nullptr; void* mtmp = nullptr;
+    // persistent state database (nsqMain.m:91-99): rows in HBM, open-addressing table of row ids
+    int64_t db_cap = 0, db_n = 0, db_samples = 0; uint64_t db_tcap = 0;
+    uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
+    double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
+    bool db_has_opts = false; relmc_solver_opts db_opts;
     // sequential track
     bool has_seq = false; SeqCase hseq; SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
@@ -56,6 +61,7 @@ struct relmc_ctx {
 namespace {
 
 const char* kNoCtx = "relmc: null context";
+void db_free(relmc_ctx* ctx);
 
 int fail(relmc_ctx* ctx, int code, const std::string& msg)
 {
@@ -503,6 +509,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, TL>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
     ctx->blocks_per_cu = bpc;
@@ -519,7 +526,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.3 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedule)"; }
+const char* relmc_version(void) { return "relmc 0.4 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedule, device state database)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
@@ -562,6 +569,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dsorted) (void)hipFree(ctx->dsorted);
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
+    db_free(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
     if (ctx->stream) (void)hipStreamDestroy(ctx->stream);
@@ -603,6 +611,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     if (nb < 1 || ng < 0 || nl < 0 || nd < 0 || d->ref_bus < 0 || d->ref_bus >= nb || !(d->base_mva > 0))
         return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
     ctx->has_case = false;
+    db_free(ctx);                  // the state database belongs to the case it was filled for
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
         ctx->tile = 0;
@@ -740,6 +749,62 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
     return RELMC_OK;
 }
 
+namespace {
+// nsqMain.m:220-229 on the device for the samples [first_index, first_index + m): outage masks (ctx->mk), sample indices
+// sorted by mask (*perm_out; stable, so every run starts with its earliest sample), run starts (ctx->mstart) and the number
+// of distinct states.  Leaves the stream synchronised.
+int memo_prepare(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m, uint32_t* nu_out, uint32_t** perm_out)
+{
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int nchunk = (ctx->ncomp + 63) / 64;
+    size_t tmp_sort = 0, tmp_scan = 0;
+    (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                    (size_t)m, 0u, 64u, ctx->stream);
+    (void)rocprim::exclusive_scan(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream);
+    const size_t tmp_need = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
+        for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
+                        (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
+        ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
+        ctx->memo_cap = 0; ctx->memo_tmp_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->mk, sizeof(uint32_t) * (size_t)m * 8));
+        HIP_TRY(ctx, hipMalloc(&ctx->mperm0, sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->mperm1, sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->mhead, sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->muid, sizeof(uint32_t) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->mstart, sizeof(uint32_t) * ((size_t)m + 1)));
+        HIP_TRY(ctx, hipMalloc(&ctx->mnu, sizeof(uint32_t) * 2));
+        HIP_TRY(ctx, hipMalloc(&ctx->mch0, sizeof(unsigned long long) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->mch1, sizeof(unsigned long long) * (size_t)m));
+        HIP_TRY(ctx, hipMalloc(&ctx->mtmp, tmp_need));
+        ctx->memo_cap = m; ctx->memo_tmp_bytes = tmp_need;
+    }
+    int64_t gb = (m + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
+    const dim3 grid((unsigned)gb), blk(256);
+    if (ctx->tile == 0) hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile24>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index, m, ctx->mk);
+    else hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile96>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index, m, ctx->mk);
+    hipLaunchKernelGGL(relmc_memo_iota_kernel, grid, blk, 0, ctx->stream, m, ctx->mperm0);
+    uint32_t* pin = ctx->mperm0; uint32_t* pout = ctx->mperm1;
+    for (int c = 0; c < nchunk; ++c) {               // LSD: stable sort by chunk 0, then 1, ...
+        hipLaunchKernelGGL(relmc_memo_chunk_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, c, m, ctx->mch0);
+        const int bits = ctx->ncomp - 64 * c < 64 ? ctx->ncomp - 64 * c : 64;
+        size_t tb = ctx->memo_tmp_bytes;
+        HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->mtmp, tb, ctx->mch0, ctx->mch1, pin, pout, (size_t)m, 0u, (unsigned)bits, ctx->stream));
+        uint32_t* t = pin; pin = pout; pout = t;
+    }
+    hipLaunchKernelGGL(relmc_memo_heads_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, m, ctx->mhead);
+    { size_t tb = ctx->memo_tmp_bytes;
+      HIP_TRY(ctx, rocprim::exclusive_scan(ctx->mtmp, tb, ctx->mhead, ctx->muid, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream)); }
+    hipLaunchKernelGGL(relmc_memo_starts_kernel, grid, blk, 0, ctx->stream, ctx->mhead, ctx->muid, m, ctx->mstart, ctx->mnu);
+    HIP_TRY(ctx, hipGetLastError());
+    uint32_t nu = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&nu, ctx->mnu, sizeof(nu), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    *nu_out = nu; *perm_out = pin;
+    return RELMC_OK;
+}
+}  // namespace
+
 // nsqMain.m:220-245 per launch: the sampled range's distinct states are evaluated once each and counted with their
 // multiplicities.  Same accumulators as relmc_nsq_accumulate (integers identical, sums up to summation order).
 int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
@@ -755,61 +820,19 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const int64_t kMaxPerLaunch = (int64_t)1 << 27;      // 32-bit weighted counters per scenario row
-    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
-    const int nchunk = (ctx->ncomp + 63) / 64;
     double ms_total = 0.0;
     int64_t distinct_total = 0;
     for (int64_t done = 0; done < n;) {
         const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
-        size_t tmp_sort = 0, tmp_scan = 0;
-        (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                        (size_t)m, 0u, 64u, ctx->stream);
-        (void)rocprim::exclusive_scan(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream);
-        const size_t tmp_need = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
-        if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
-            for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
-                            (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
-            ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
-            ctx->memo_cap = 0; ctx->memo_tmp_bytes = 0;
-            HIP_TRY(ctx, hipMalloc(&ctx->mk, sizeof(uint32_t) * (size_t)m * 8));
-            HIP_TRY(ctx, hipMalloc(&ctx->mperm0, sizeof(uint32_t) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->mperm1, sizeof(uint32_t) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->mhead, sizeof(uint32_t) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->muid, sizeof(uint32_t) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->mstart, sizeof(uint32_t) * ((size_t)m + 1)));
-            HIP_TRY(ctx, hipMalloc(&ctx->mnu, sizeof(uint32_t)));
-            HIP_TRY(ctx, hipMalloc(&ctx->mch0, sizeof(unsigned long long) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->mch1, sizeof(unsigned long long) * (size_t)m));
-            HIP_TRY(ctx, hipMalloc(&ctx->mtmp, tmp_need));
-            ctx->memo_cap = m; ctx->memo_tmp_bytes = tmp_need;
-        }
-        int64_t gb = (m + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
-        const dim3 grid((unsigned)gb), blk(256);
         const auto t0 = std::chrono::steady_clock::now();
-        if (ctx->tile == 0) hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile24>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index + (uint64_t)done, m, ctx->mk);
-        else hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile96>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index + (uint64_t)done, m, ctx->mk);
-        hipLaunchKernelGGL(relmc_memo_iota_kernel, grid, blk, 0, ctx->stream, m, ctx->mperm0);
-        uint32_t* pin = ctx->mperm0; uint32_t* pout = ctx->mperm1;
-        for (int c = 0; c < nchunk; ++c) {               // LSD: stable sort by chunk 0, then 1, ...
-            hipLaunchKernelGGL(relmc_memo_chunk_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, c, m, ctx->mch0);
-            const int bits = ctx->ncomp - 64 * c < 64 ? ctx->ncomp - 64 * c : 64;
-            size_t tb = ctx->memo_tmp_bytes;
-            HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->mtmp, tb, ctx->mch0, ctx->mch1, pin, pout, (size_t)m, 0u, (unsigned)bits, ctx->stream));
-            uint32_t* t = pin; pin = pout; pout = t;
-        }
-        hipLaunchKernelGGL(relmc_memo_heads_kernel, grid, blk, 0, ctx->stream, ctx->mk, pin, ow, m, ctx->mhead);
-        { size_t tb = ctx->memo_tmp_bytes;
-          HIP_TRY(ctx, rocprim::exclusive_scan(ctx->mtmp, tb, ctx->mhead, ctx->muid, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream)); }
-        hipLaunchKernelGGL(relmc_memo_starts_kernel, grid, blk, 0, ctx->stream, ctx->mhead, ctx->muid, m, ctx->mstart, ctx->mnu);
-        HIP_TRY(ctx, hipGetLastError());
-        uint32_t nu = 0;
-        HIP_TRY(ctx, hipMemcpyAsync(&nu, ctx->mnu, sizeof(nu), hipMemcpyDeviceToHost, ctx->stream));
-        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        uint32_t nu = 0; uint32_t* pin = nullptr;
+        int rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &pin);
+        if (rc) return rc;
         const double prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
         EvalArgs a = make_args(o);
         a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
         int rows = 0;
-        int rc = launch_eval<3>(ctx, a, &rows);
+        rc = launch_eval<3>(ctx, a, &rows);
         if (rc) return rc;
         rc = launch_finalize(ctx, rows);
         if (rc) return rc;
@@ -824,6 +847,221 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
     }
     ctx->last_kernel_ms = ms_total;
     if (n_distinct_out) *n_distinct_out = distinct_total;
+    return RELMC_OK;
+}
+
+// ---- persistent state database across batches: nsqMain.m:91-99 (layout), 220-245 (dedupe, count bumps), 257-278 (new
+// states evaluated and appended), 282-301 + 348-349 + 366-376 (indices from the whole database) ------------------------
+namespace {
+void db_free(relmc_ctx* ctx)
+{
+    for (void* p : {(void*)ctx->db_keys, (void*)ctx->db_count, (void*)ctx->db_dns, (void*)ctx->db_meta, (void*)ctx->db_nodal, (void*)ctx->db_table,
+                    (void*)ctx->db_partial}) if (p) (void)hipFree(p);
+    ctx->db_keys = nullptr; ctx->db_count = nullptr; ctx->db_dns = nullptr; ctx->db_meta = nullptr; ctx->db_nodal = nullptr; ctx->db_table = nullptr;
+    ctx->db_partial = nullptr; ctx->db_partial_cap = 0;
+    ctx->db_cap = 0; ctx->db_n = 0; ctx->db_samples = 0; ctx->db_tcap = 0; ctx->db_has_opts = false;
+}
+
+// room for `need` rows: the arrays double (contents copied on the device) and the table of row ids is rebuilt
+int db_ensure(relmc_ctx* ctx, int64_t need)
+{
+    if (need <= ctx->db_cap) return RELMC_OK;
+    if (need >= (int64_t)0xfffffff0ll) return fail(ctx, RELMC_ERR_UNSUPPORTED, "state database: more than 2^32 rows");
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int nb = ctx->nb;
+    int64_t cap = ctx->db_cap ? ctx->db_cap * 2 : (int64_t)1 << 16;
+    while (cap < need) cap *= 2;
+    uint32_t* keys = nullptr; unsigned long long* count = nullptr; double* dns = nullptr; int32_t* meta = nullptr; double* nodal = nullptr; uint32_t* table = nullptr;
+    uint64_t tcap = 1; while (tcap < (uint64_t)cap * 2) tcap <<= 1;
+    auto bail = [&]() { (void)hipFree(keys); (void)hipFree(count); (void)hipFree(dns); (void)hipFree(meta); (void)hipFree(nodal); (void)hipFree(table); };
+    if (hipMalloc(&keys, sizeof(uint32_t) * (size_t)cap * ow) != hipSuccess || hipMalloc(&count, sizeof(unsigned long long) * (size_t)cap) != hipSuccess ||
+        hipMalloc(&dns, sizeof(double) * (size_t)cap) != hipSuccess || hipMalloc(&meta, sizeof(int32_t) * (size_t)cap) != hipSuccess ||
+        hipMalloc(&nodal, sizeof(double) * (size_t)cap * nb) != hipSuccess || hipMalloc(&table, sizeof(uint32_t) * tcap) != hipSuccess) {
+        bail(); return fail(ctx, RELMC_ERR_HIP, "state database: device allocation failed");
+    }
+    const size_t n = (size_t)ctx->db_n;
+    bool ok = hipMemsetAsync(table, 0xff, sizeof(uint32_t) * tcap, ctx->stream) == hipSuccess;
+    if (n) {
+        ok = ok && hipMemcpyAsync(keys, ctx->db_keys, sizeof(uint32_t) * n * ow, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(count, ctx->db_count, sizeof(unsigned long long) * n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(dns, ctx->db_dns, sizeof(double) * n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(meta, ctx->db_meta, sizeof(int32_t) * n, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess &&
+             hipMemcpyAsync(nodal, ctx->db_nodal, sizeof(double) * n * nb, hipMemcpyDeviceToDevice, ctx->stream) == hipSuccess;
+        if (ok) {
+            int64_t gb = ((int64_t)n + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
+            hipLaunchKernelGGL(relmc_db_rehash_kernel, dim3((unsigned)gb), dim3(256), 0, ctx->stream, keys, (uint64_t)n, ow, table, tcap - 1);
+            ok = hipGetLastError() == hipSuccess;
+        }
+    }
+    ok = ok && hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) { bail(); return fail(ctx, RELMC_ERR_HIP, "state database: growing the arrays failed"); }
+    for (void* p : {(void*)ctx->db_keys, (void*)ctx->db_count, (void*)ctx->db_dns, (void*)ctx->db_meta, (void*)ctx->db_nodal, (void*)ctx->db_table}) if (p) (void)hipFree(p);
+    ctx->db_keys = keys; ctx->db_count = count; ctx->db_dns = dns; ctx->db_meta = meta; ctx->db_nodal = nodal; ctx->db_table = table;
+    ctx->db_cap = cap; ctx->db_tcap = tcap;
+    return RELMC_OK;
+}
+
+bool same_opts(const relmc_solver_opts& a, const relmc_solver_opts& b)
+{
+    return a.singular_policy == b.singular_policy && a.max_it == b.max_it && a.feastol == b.feastol && a.gradtol == b.gradtol && a.comptol == b.comptol &&
+           a.costtol == b.costtol && a.xi == b.xi && a.sigma == b.sigma && a.z0 == b.z0 && a.alpha_min == b.alpha_min && a.max_stepsize == b.max_stepsize;
+}
+
+// nsqMain.m:282-301, 348-349, 366-376: count-weighted sums over every row of the database -> *acc_out
+int db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out)
+{
+    relmc_acc_zero(acc_out);
+    if (ctx->db_n == 0) return RELMC_OK;
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    // the split into blocks depends on the number of rows only, so the fp64 sums do not depend on how the rows arrived
+    const uint64_t rows = (uint64_t)ctx->db_n;
+    const uint64_t chunk = 2048;
+    uint64_t nblk = (rows + chunk - 1) / chunk;
+    uint64_t per = chunk;
+    if (nblk > 4096) { per = (rows + 4095) / 4096; nblk = (rows + per - 1) / per; }
+    if ((int)nblk > ctx->db_partial_cap) {
+        if (ctx->db_partial) (void)hipFree(ctx->db_partial);
+        ctx->db_partial = nullptr; ctx->db_partial_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->db_partial, sizeof(DevAcc) * 4096));
+        ctx->db_partial_cap = 4096;
+    }
+    hipLaunchKernelGGL(relmc_db_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ow, ctx->nb, ctx->ncomp, 1e-4, ctx->db_keys, ctx->db_count,
+                       ctx->db_dns, ctx->db_meta, ctx->db_nodal, rows, per, ctx->db_partial);
+    hipLaunchKernelGGL(relmc_db_final_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->db_partial, (int)nblk, ctx->dacc);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RELMC_OK;
+}
+}  // namespace
+
+int32_t relmc_db_reset(relmc_ctx* ctx)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    ctx->db_n = 0; ctx->db_samples = 0; ctx->db_has_opts = false;
+    if (ctx->db_table) { HIP_TRY(ctx, hipMemsetAsync(ctx->db_table, 0xff, sizeof(uint32_t) * ctx->db_tcap, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
+    return RELMC_OK;
+}
+
+int32_t relmc_db_size(const relmc_ctx* ctx, int64_t* rows_out, int64_t* samples_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (rows_out) *rows_out = ctx->db_n;
+    if (samples_out) *samples_out = ctx->db_samples;
+    return RELMC_OK;
+}
+
+int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
+                           relmc_acc* acc_out, relmc_db_stats* stats_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_db_batch: no case loaded");
+    if (n < 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_db_batch: bad arguments");
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    if (ctx->db_has_opts && ctx->db_n > 0 && !same_opts(o, ctx->db_opts))
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_db_batch: the database holds results of other solver options (relmc_db_reset first)");
+    ctx->db_opts = o; ctx->db_has_opts = true;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int64_t kMaxPerLaunch = (int64_t)1 << 27;
+    double ms_total = 0.0;
+    int64_t new_total = 0, distinct_total = 0;
+    for (int64_t done = 0; done < n;) {
+        const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
+        const auto t0 = std::chrono::steady_clock::now();
+        uint32_t nu = 0; uint32_t* perm = nullptr;
+        int rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &perm);      // :220-229
+        if (rc) return rc;
+        rc = db_ensure(ctx, ctx->db_n + (int64_t)nu);
+        if (rc) return rc;
+        // :232-245: states already in the database collect their counts, the others are flagged.  Scratch arrays of the
+        // run-length step are dead by now and reused: first-sample index (sort key) / distinct-state id pairs.
+        uint32_t* first_idx = ctx->mhead; uint32_t* uid = ctx->muid;
+        uint32_t* first_sorted = reinterpret_cast<uint32_t*>(ctx->mch0); uint32_t* u_sorted = reinterpret_cast<uint32_t*>(ctx->mch1);
+        uint32_t* dnew = ctx->mnu + 1;
+        HIP_TRY(ctx, hipMemsetAsync(dnew, 0, sizeof(uint32_t), ctx->stream));
+        int64_t gb = ((int64_t)nu + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16; if (gb < 1) gb = 1;
+        hipLaunchKernelGGL(relmc_db_lookup_kernel, dim3((unsigned)gb), dim3(256), 0, ctx->stream, ctx->mk, perm, ctx->mstart, nu, ow, ctx->db_keys, ctx->db_count,
+                           ctx->db_table, ctx->db_tcap - 1, first_idx, uid, dnew);
+        HIP_TRY(ctx, hipGetLastError());
+        uint32_t n_new = 0;
+        HIP_TRY(ctx, hipMemcpyAsync(&n_new, dnew, sizeof(n_new), hipMemcpyDeviceToHost, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        double eval_ms = 0.0;
+        if (n_new > 0) {
+            // new rows in the order of first appearance (unique(...,'stable'), :220): sort the flagged states by first sample index
+            size_t tb = ctx->memo_tmp_bytes, need = 0;
+            (void)rocprim::radix_sort_pairs(nullptr, need, first_idx, first_sorted, uid, u_sorted, (size_t)nu, 0u, 32u, ctx->stream);
+            if (need > tb) return fail(ctx, RELMC_ERR_HIP, "relmc_nsq_db_batch: sort scratch too small");
+            HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->mtmp, tb, first_idx, first_sorted, uid, u_sorted, (size_t)nu, 0u, 32u, ctx->stream));
+            int64_t gi = ((int64_t)n_new + 255) / 256; if (gi > (int64_t)ctx->num_cu * 16) gi = (int64_t)ctx->num_cu * 16;
+            hipLaunchKernelGGL(relmc_db_insert_kernel, dim3((unsigned)gi), dim3(256), 0, ctx->stream, ctx->mk, perm, ctx->mstart, u_sorted, n_new, ow, (uint64_t)ctx->db_n,
+                               ctx->db_keys, ctx->db_count, ctx->db_table, ctx->db_tcap - 1);
+            HIP_TRY(ctx, hipGetLastError());
+            // :257-278: evaluate the new states, results into their rows
+            EvalArgs a = make_args(o);
+            a.n = (int64_t)n_new; a.memo_keys = ctx->db_keys; a.db_first = ctx->db_n;
+            a.dns = ctx->db_dns; a.status = ctx->db_meta; a.nodal = ctx->db_nodal;
+            int rows = 0;
+            rc = launch_eval<4>(ctx, a, &rows);
+            if (rc) return rc;
+            rc = finish_timing(ctx);
+            if (rc) return rc;
+            eval_ms = ctx->last_kernel_ms;
+            ctx->db_n += (int64_t)n_new;
+        }
+        ctx->db_samples += m;
+        (void)eval_ms;
+        ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+        new_total += n_new; distinct_total += nu;
+        done += m;
+    }
+    if (acc_out) {
+        const auto t0 = std::chrono::steady_clock::now();
+        int rc = db_accumulate(ctx, acc_out);                                               // :282-301, 348-349, 366-376
+        if (rc) return rc;
+        ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+    }
+    ctx->last_kernel_ms = ms_total;       // sampling + dedupe + lookup + evaluation of the new states + database reduction (host-timed)
+    if (stats_out) { stats_out->rows = ctx->db_n; stats_out->samples = ctx->db_samples; stats_out->new_rows = new_total; stats_out->batch_distinct = distinct_total; }
+    return RELMC_OK;
+}
+
+int32_t relmc_db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out)
+{
+    if (!ctx || !acc_out) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_db_accumulate: no case loaded");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    return db_accumulate(ctx, acc_out);
+}
+
+int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8_t* states_host, int64_t* count_host, double* dns_host,
+                        int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_db_export: no case loaded");
+    if (first_row < 0 || n_rows < 0 || first_row + n_rows > ctx->db_n) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_export: row range outside the database");
+    if (n_rows == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int ncomp = ctx->ncomp, nb = ctx->nb;
+    const size_t n = (size_t)n_rows, f = (size_t)first_row;
+    std::vector<uint32_t> keys; std::vector<unsigned long long> cnt; std::vector<double> dns; std::vector<int32_t> meta;
+    if (states_host) { keys.resize(n * ow); HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->db_keys + f * ow, sizeof(uint32_t) * n * ow, hipMemcpyDeviceToHost)); }
+    if (count_host) { cnt.resize(n); HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->db_count + f, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost)); }
+    if (dns_host || flag_host) { dns.resize(n); HIP_TRY(ctx, hipMemcpy(dns.data(), ctx->db_dns + f, sizeof(double) * n, hipMemcpyDeviceToHost)); }
+    if (status_host || iters_host) { meta.resize(n); HIP_TRY(ctx, hipMemcpy(meta.data(), ctx->db_meta + f, sizeof(int32_t) * n, hipMemcpyDeviceToHost)); }
+    if (nodal_host) HIP_TRY(ctx, hipMemcpy(nodal_host, ctx->db_nodal + f * nb, sizeof(double) * n * nb, hipMemcpyDeviceToHost));
+    for (size_t r = 0; r < n; ++r) {
+        if (states_host) for (int k = 0; k < ncomp; ++k) states_host[r * ncomp + k] = (uint8_t)((keys[r * ow + (k >> 5)] >> (k & 31)) & 1u);
+        if (count_host) count_host[r] = (int64_t)cnt[r];
+        if (dns_host) dns_host[r] = dns[r];
+        if (flag_host) flag_host[r] = dns[r] > 1e-4 ? 1 : 0;                  // nsqMain.m:270
+        if (status_host) status_host[r] = meta[r] & 3;
+        if (iters_host) iters_host[r] = (int32_t)((uint32_t)meta[r] >> 8);
+    }
     return RELMC_OK;
 }
 
@@ -1099,14 +1337,21 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     const int nb = ctx->nb, ncomp = ctx->ncomp;
     double beta = INFINITY, kernel_ms = 0.0;
     int64_t done = 0, cp = 0;
+    if (o->distinct_states == 2) { const int rc0 = relmc_db_reset(ctx); if (rc0) return rc0; }
     while (beta > o->beta_limit && done < o->max_samples) {
         const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;
         relmc_acc part;
-        int rc = o->distinct_states ? relmc_nsq_accumulate_distinct(ctx, o->seed, (uint64_t)done, m, &o->solver, &part, nullptr)
+        int rc;
+        if (o->distinct_states == 2) {
+            // the reference's own loop body: persistent unique-state database, indices recomputed from all of its rows
+            rc = relmc_nsq_db_batch(ctx, o->seed, (uint64_t)done, m, &o->solver, &res->acc, nullptr);
+        } else {
+            rc = o->distinct_states ? relmc_nsq_accumulate_distinct(ctx, o->seed, (uint64_t)done, m, &o->solver, &part, nullptr)
                                     : relmc_nsq_accumulate(ctx, o->seed, (uint64_t)done, m, &o->solver, &part);
+            if (rc == RELMC_OK) relmc_acc_merge(&res->acc, &part);
+        }
         if (rc) return rc;
         kernel_ms += ctx->last_kernel_ms;
-        relmc_acc_merge(&res->acc, &part);
         done += m;
         relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
         beta = res->idx.beta;
@@ -1118,7 +1363,8 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         }
         cp++;
     }
-    res->checkpoints = cp;
+    res->checkpoints = cp < o->history_cap ? cp : o->history_cap;     // history entries written
+    res->batches = cp;
     res->converged = beta <= o->beta_limit ? 1 : 0;
     res->kernel_seconds = kernel_ms * 1e-3;
     res->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();

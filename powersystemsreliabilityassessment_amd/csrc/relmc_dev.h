@@ -128,6 +128,9 @@ struct EvalArgs {
     const uint32_t* memo_keys;      // [n][OW] outage masks of the sampled range
     const uint32_t* memo_perm;      // [n] sample indices sorted by mask
     const uint32_t* memo_start;     // [n_distinct + 1] first sorted position of every distinct mask
+    // MODE 4 (rows of the persistent state database): scenario u = row db_first + u, key words at memo_keys[row][OW],
+    // results go to dns[row], status[row] (packed) and nodal[row][nb]
+    int64_t db_first;
 };
 
 }  // namespace relmc

@@ -154,6 +154,8 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 //         load scale from the hourly curve, curtailment written to curt[year][hour]
 // MODE 3: distinct states of a sampled range with their multiplicities (the reference's unique-state database,
 //         nsqMain.m:220-245, per launch): accumulators are weighted by the multiplicity
+// MODE 4: new rows of the persistent state database (nsqMain.m:257-278): scenario u = database row db_first + u, state from
+//         the row's key words, results written into the row (dns, status/iterations, nodal shed); no accumulation
 template <int MODE, class TL>
 __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
@@ -344,6 +346,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 const uint32_t s0 = a.memo_start[sidx];
                 wgt = a.memo_start[sidx + 1] - s0;
                 if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)a.memo_perm[s0] * OW + rlane];
+            } else if (MODE == 4) {
+                if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)(a.db_first + sidx) * OW + rlane];
             } else {
                 if (rlane < OW) OB[rlane] = 0u;
                 RELOAD_FENCE();
@@ -1042,13 +1046,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     const double v = ip[s] * base - C.i_pmin_mw[j] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
-                if (shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
-                if (fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += wgt;
+                if (MODE != 4 && shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
+                if (MODE != 4 && fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += wgt;
             }
 #pragma unroll
             for (int s = 0; s < LS; ++s)
-                if (fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
-            if (rlane == 0) {                       // row-uniform quantities: one lane per scenario row
+                if (MODE != 4 && fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
+            if (MODE != 4 && rlane == 0) {          // row-uniform quantities: one lane per scenario row
                 PA.n += wgt;
                 if (dns != 0.0) {
                     if (MODE == 3) { PA.dns = __builtin_fma((double)wgt, dns, PA.dns); PA.dns2 = __builtin_fma((double)wgt * dns, dns, PA.dns2); }
@@ -1061,13 +1065,18 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 PA.iters += (uint32_t)it * wgt;
             }
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
-            if (MODE == 1) {
+            if (MODE == 1 || MODE == 4) {
+                const int64_t oidx = MODE == 4 ? a.db_first + sidx : sidx;       // MODE 4: the database row
 #pragma unroll
                 for (int s = 0; s < IS; ++s) if (RW * s + rlane < nip) IR[4 * (RW * s + rlane)] = shed[s];
                 if (rlane == 0) {
-                    a.dns[sidx] = dns;
-                    if (a.status) a.status[sidx] = status;
-                    if (a.iters) a.iters[sidx] = it;
+                    a.dns[oidx] = dns;
+                    // database rows pack what the estimators need beside dns: status | relaxed << 2 | iterations << 8
+                    if (MODE == 4) a.status[oidx] = status | (infeas ? 4 : 0) | (it << 8);
+                    else {
+                        if (a.status) a.status[oidx] = status;
+                        if (a.iters) a.iters[oidx] = it;
+                    }
                 }
                 if (a.nodal) {
 #pragma unroll
@@ -1075,7 +1084,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const int i = RW * t + rlane;
                         if (i < nb) {
                             const int vj = C.b_vinj[i];
-                            a.nodal[sidx * nb + C.b_ext[i]] = vj >= 0 ? IR[4 * vj] : 0.0;
+                            a.nodal[oidx * nb + C.b_ext[i]] = vj >= 0 ? IR[4 * vj] : 0.0;
                         }
                     }
                 }
@@ -1232,6 +1241,158 @@ __global__ void __launch_bounds__(256) relmc_memo_starts_kernel(const uint32_t* 
     for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
         if (head[j]) start[uid[j]] = (uint32_t)j;
         if (j == n - 1) { const uint32_t nu = uid[j] + head[j]; start[nu] = (uint32_t)n; *n_distinct_out = nu; }
+    }
+}
+
+// ---- persistent state database (nsqMain.m:91-99, 220-278): one row per distinct state ever sampled -------------------
+// Rows live in HBM as parallel arrays keys[cap][ow] (outage mask words), count[cap], dns[cap], meta[cap] (status |
+// relaxed << 2 | iterations << 8), nodal[cap][nb]; an open-addressing table of row ids (linear probing, full-key
+// compares) finds a state.  Rows are appended in the order of first appearance in the global sample stream, which makes
+// the database (and every fp64 sum over it) independent of the batch size.
+constexpr uint32_t DB_EMPTY = 0xffffffffu;
+DEVFI uint64_t db_hash(const uint32_t* k, int ow)
+{
+    uint64_t h = 0x9E3779B97F4A7C15ull;
+    for (int q = 0; q < ow; ++q) { h = (h ^ k[q]) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
+    return h;
+}
+
+// nsqMain.m:232-245 for the distinct states of one batch (unique within the batch, so no two threads touch the same row):
+// known state -> its count grows by the multiplicity; unknown -> flagged with the index of its first sample (the sort key
+// that orders the new rows by first appearance); states[u] = keys[perm[start[u]]], multiplicity start[u+1] - start[u]
+__global__ void __launch_bounds__(256) relmc_db_lookup_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                              const uint32_t* __restrict__ start, uint32_t nu, int ow,
+                                                              const uint32_t* __restrict__ db_keys, unsigned long long* __restrict__ db_count,
+                                                              const uint32_t* __restrict__ table, uint64_t tmask,
+                                                              uint32_t* __restrict__ first_idx, uint32_t* __restrict__ uid, uint32_t* __restrict__ n_new)
+{
+    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nu; u += gridDim.x * blockDim.x) {
+        const uint32_t s0 = start[u], first = perm[s0];          // stable sort: the run's first entry is the earliest sample
+        const uint32_t* k = keys + (size_t)first * ow;
+        uint64_t h = db_hash(k, ow) & tmask;
+        uint32_t found = DB_EMPTY;
+        for (;;) {
+            const uint32_t r = table[h];
+            if (r == DB_EMPTY) break;
+            const uint32_t* dk = db_keys + (size_t)r * ow;
+            bool eq = true;
+            for (int q = 0; q < ow; ++q) eq = eq && dk[q] == k[q];
+            if (eq) { found = r; break; }
+            h = (h + 1) & tmask;
+        }
+        uid[u] = u;
+        if (found != DB_EMPTY) { db_count[found] += (unsigned long long)(start[u + 1] - s0); first_idx[u] = DB_EMPTY; }
+        else { first_idx[u] = first; atomicAdd(n_new, 1u); }
+    }
+}
+
+// nsqMain.m:269-278, the state and count columns of the new rows: row db_n + k = k-th new state in order of first appearance
+__global__ void __launch_bounds__(256) relmc_db_insert_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
+                                                              const uint32_t* __restrict__ start, const uint32_t* __restrict__ sorted_u, uint32_t n_new,
+                                                              int ow, uint64_t db_n, uint32_t* __restrict__ db_keys,
+                                                              unsigned long long* __restrict__ db_count, uint32_t* __restrict__ table, uint64_t tmask)
+{
+    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_new; k += gridDim.x * blockDim.x) {
+        const uint32_t u = sorted_u[k], s0 = start[u];
+        const uint32_t* src = keys + (size_t)perm[s0] * ow;
+        const uint64_t row = db_n + k;
+        uint32_t* dst = db_keys + row * ow;
+        for (int q = 0; q < ow; ++q) dst[q] = src[q];
+        db_count[row] = (unsigned long long)(start[u + 1] - s0);
+        uint64_t h = db_hash(src, ow) & tmask;
+        while (atomicCAS(&table[h], DB_EMPTY, (uint32_t)row) != DB_EMPTY) h = (h + 1) & tmask;   // keys are distinct: claim the first free slot
+    }
+}
+
+// table of row ids rebuilt after the database has grown
+__global__ void __launch_bounds__(256) relmc_db_rehash_kernel(const uint32_t* __restrict__ db_keys, uint64_t rows, int ow,
+                                                              uint32_t* __restrict__ table, uint64_t tmask)
+{
+    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
+        uint64_t h = db_hash(db_keys + r * ow, ow) & tmask;
+        while (atomicCAS(&table[h], DB_EMPTY, (uint32_t)r) != DB_EMPTY) h = (h + 1) & tmask;
+    }
+}
+
+// nsqMain.m:282-301, 348-349, 366-376 over the whole database: the count-weighted sums of the rows (stage 1: one partial
+// accumulator image per block of `chunk` consecutive rows; fp64 sums in a fixed order, integer sums by LDS atomics)
+__global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, int ncomp, double fail_threshold, const uint32_t* __restrict__ keys,
+                                                              const unsigned long long* __restrict__ count, const double* __restrict__ dns,
+                                                              const int32_t* __restrict__ meta, const double* __restrict__ nodal,
+                                                              uint64_t rows, uint64_t chunk, DevAcc* __restrict__ partial)
+{
+    __shared__ unsigned long long si[6 + 256];
+    __shared__ double sd[2][256];
+    __shared__ double sn[8][128];
+    const int t = threadIdx.x;
+    for (int k = t; k < 6 + 256; k += 256) si[k] = 0ull;
+    __syncthreads();
+    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < rows ? lo + chunk : rows;
+    unsigned long long c_n = 0, c_fail = 0, c_sing = 0, c_inf = 0, c_nc = 0, c_it = 0;
+    double s1 = 0.0, s2 = 0.0;
+    for (uint64_t r = lo + t; r < hi; r += 256) {
+        const unsigned long long c = count[r];
+        const double d = dns[r];
+        const uint32_t m = (uint32_t)meta[r];
+        const uint32_t st = m & 3u;
+        c_n += c;
+        c_it += c * (unsigned long long)(m >> 8);
+        if (st == 3u) c_sing += c;
+        if (st == 1u || st == 2u) c_nc += c;
+        if (m & 4u) c_inf += c;
+        if (d != 0.0) { const double cd = (double)c; s1 = __builtin_fma(cd, d, s1); s2 = __builtin_fma(cd * d, d, s2); }
+        if (d > fail_threshold) {                        // nsqMain.m:270
+            c_fail += c;
+            for (int q = 0; q < ow; ++q) {
+                uint32_t w = keys[r * ow + q];
+                while (w) { const int b = __ffs((int)w) - 1; w &= w - 1; atomicAdd(&si[6 + 32 * q + b], c); }
+            }
+        }
+    }
+    atomicAdd(&si[0], c_n); atomicAdd(&si[1], c_fail); atomicAdd(&si[2], c_sing); atomicAdd(&si[3], c_inf); atomicAdd(&si[4], c_nc); atomicAdd(&si[5], c_it);
+    sd[0][t] = s1; sd[1][t] = s2;
+    // nodal columns: thread (g, bl) sums bus columns bl, bl + 32, ... over the rows lo + g, lo + g + 8, ...
+    const int g = t >> 5, bl = t & 31;
+    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
+    for (uint64_t r = lo + g; r < hi; r += 8) {
+        if (dns[r] > 0.0) {                              // mc_simulation.m:65: nodal shed only where load was curtailed
+            const double cd = (double)count[r];
+            const double* nr = nodal + r * nb;
+            if (bl < nb) a0 = __builtin_fma(cd, nr[bl], a0);
+            if (bl + 32 < nb) a1 = __builtin_fma(cd, nr[bl + 32], a1);
+            if (bl + 64 < nb) a2 = __builtin_fma(cd, nr[bl + 64], a2);
+            if (bl + 96 < nb) a3 = __builtin_fma(cd, nr[bl + 96], a3);
+        }
+    }
+    sn[g][bl] = a0; sn[g][bl + 32] = a1; sn[g][bl + 64] = a2; sn[g][bl + 96] = a3;
+    __syncthreads();
+    for (int off = 128; off > 0; off >>= 1) {
+        if (t < off) { sd[0][t] += sd[0][t + off]; sd[1][t] += sd[1][t + off]; }
+        __syncthreads();
+    }
+    DevAcc& out = partial[blockIdx.x];
+    long long* oi = reinterpret_cast<long long*>(&out);
+    for (int k = t; k < 6 + 256; k += 256) oi[k] = (long long)si[k];
+    if (t == 0) { out.sum_dns = sd[0][0]; out.sum_dns2 = sd[1][0]; }
+    if (t < 128) out.sum_nodal[t] = ((sn[0][t] + sn[1][t]) + (sn[2][t] + sn[3][t])) + ((sn[4][t] + sn[5][t]) + (sn[6][t] + sn[7][t]));
+    (void)ncomp;
+}
+
+// stage 2: one wavefront per accumulator word sums the block partials lane-strided and combines them by a fixed butterfly
+__global__ void __launch_bounds__(64) relmc_db_final_kernel(const DevAcc* __restrict__ partial, int nblocks, DevAcc* __restrict__ out)
+{
+    constexpr int NI = 6 + 256;
+    const int item = blockIdx.x, lane = threadIdx.x;
+    long long si = 0; double sd = 0.0;
+    for (int b = lane; b < nblocks; b += 64) {
+        if (item < NI) si += reinterpret_cast<const long long*>(&partial[b])[item];
+        else sd += (&partial[b].sum_dns)[item - NI];
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) { si += __shfl_xor(si, off); sd += __shfl_xor(sd, off); }
+    if (lane == 0) {
+        if (item < NI) reinterpret_cast<long long*>(out)[item] = si;
+        else (&out->sum_dns)[item - NI] = sd;
     }
 }
 

@@ -172,15 +172,22 @@ def test_full_size_properties(engine, golden):
 
 
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
-def test_distinct_state_path_equals_per_sample_path(engine, policy):
+def test_distinct_state_path_equals_per_sample_path(engine, oracle, policy):
     """nsqMain.m:220-245 on the device (sort the outage masks, solve each distinct state once, weight by multiplicity)
-    gives the accumulators of the per-sample path: integers identical, sums up to summation order."""
+    gives the accumulators of the per-sample path: integers identical, sums up to summation order — and those of the
+    oracle evaluated through its own state memo."""
     n, seed, first = 300000, 3, 10**9
     plain = engine.nsq_accumulate(seed, first, n, api.mpoption(policy))
     acc, nd = engine.nsq_accumulate_distinct(seed, first, n, api.mpoption(policy))
     pi, pd = plain.to_arrays(); ai, ad = acc.to_arrays()
     assert np.array_equal(ai, pi)
     np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
+    ref = oracle.nsq_accumulate(seed, first, n, policy, memo=True)
+    ri, rd = ref.to_arrays()
+    assert np.array_equal(ai[:5], ri[:5]) and np.array_equal(ai[6:], ri[6:])
+    assert abs(int(ai[5]) - int(ri[5])) <= n // 200
+    np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8)
+    np.testing.assert_allclose(ad[2:], rd[2:], rtol=2e-3, atol=1e-3)
     assert 0.03 * n < nd < 0.15 * n                       # SURVEY 8f rank 4: 9.2 % distinct at 1e5, 2.9 % at 2e6
     # the run loop with the option set walks the same beta curve
     a = engine.nsqMain(beta_limit=0.02, max_iterations=400000, samples_per_batch=50000, seed=2, mpopt=api.mpoption(policy))
@@ -231,3 +238,92 @@ def test_fused_path_ragged_ranges(engine, oracle):
         assert np.array_equal(ai[:5], ri[:5]) and np.array_equal(ai[6:], ri[6:]), n
         np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8, atol=1e-9)
     assert engine.nsq_accumulate(21, 777, 0).n == 0
+
+
+# ---- the reference's persistent unique-state database on the device (nsqMain.m:91-99, 220-278) -------------------------
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_state_database_matches_oracle_database(engine, oracle, policy):
+    """Device database vs the oracle's literal restatement of the nsqMain loop in database form, same seed:
+    rows (states, counts, flags, status) identical and in the same order, dns <= 1e-6 MW, histories, accumulators."""
+    n, batch, seed = 300_000, 50_000, 4
+    r = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=batch, seed=seed, mpopt=api.mpoption(policy),
+                       distinct_states="database")
+    db = engine.db_export()
+    ref = oracle.nsq_database(seed, 0.0, n, batch, policy=policy, max_rows=n)
+    assert r.current_iteration == n and r.database_row_count == len(ref["count"]) == len(db["count"])
+    assert np.array_equal(db["states"], ref["states"])                # same rows in the same (first-appearance) order
+    assert np.array_equal(db["count"], ref["count"]) and db["count"].sum() == n
+    assert np.array_equal(db["flag"], ref["flag"]) and np.array_equal(db["status"], ref["status"])
+    np.testing.assert_allclose(db["dns"], ref["dns"], rtol=0, atol=DNS_TOL)
+    dit = np.abs(db["iters"] - ref["iters"])
+    assert dit.max() <= 1 and (dit > 0).mean() < 0.01
+    shed = db["dns"] > 0
+    np.testing.assert_allclose(db["nodal"].sum(1)[shed], db["dns"][shed], rtol=0, atol=2e-2)
+    assert np.all(db["nodal"][~shed] == 0)
+    # histories (nsqMain.m:304-308) and final indices
+    np.testing.assert_allclose(r.edns_history, ref["edns_history"], rtol=1e-9)
+    np.testing.assert_allclose(r.beta_history, ref["beta_history"], rtol=1e-7)
+    np.testing.assert_allclose(r.plc_history, ref["plc_history"], rtol=0, atol=1e-15)
+    ai, ad = r.acc.to_arrays(); ri, rd = ref["acc"].to_arrays()
+    assert np.array_equal(ai[:5], ri[:5]) and np.array_equal(ai[6:], ri[6:])
+    assert abs(int(ai[5]) - int(ri[5])) <= n // 200
+    np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8)
+    np.testing.assert_allclose(ad[2:], rd[2:], rtol=2e-3, atol=1e-3)
+    # ... and the per-sample device path and the oracle's memo mode
+    plain = engine.nsq_accumulate(seed, 0, n, api.mpoption(policy))
+    pi, pd = plain.to_arrays()
+    assert np.array_equal(ai, pi)
+    np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
+    memo = oracle.nsq_accumulate(seed, 0, n, policy, memo=True)
+    mi, md = memo.to_arrays()
+    assert np.array_equal(ai[:5], mi[:5]) and np.array_equal(ai[6:], mi[6:])
+    np.testing.assert_allclose(ad[:2], md[:2], rtol=1e-8)
+
+
+def test_state_database_batch_size_independent(engine):
+    """The database is a function of (seed, samples drawn): the reference's batch of 100 and one big batch give the same
+    rows in the same order and bit-identical accumulators; known states are never solved twice."""
+    seed, n = 9, 20_000
+    engine.db_reset()
+    tot_new = 0
+    for k in range(n // 100):
+        acc_a, st = engine.nsq_db_batch(seed, 100 * k, 100)
+        tot_new += st.new_rows
+        assert st.batch_distinct <= 100 and st.samples == 100 * (k + 1)
+    a = engine.db_export()
+    assert tot_new == len(a["count"]) == engine.db_size()[0]
+    engine.db_reset()
+    acc_b, st = engine.nsq_db_batch(seed, 0, n)
+    b = engine.db_export()
+    assert st.new_rows == st.rows == len(b["count"]) and st.batch_distinct == st.rows
+    for k in ("states", "count", "dns", "flag", "nodal", "status", "iters"):
+        assert np.array_equal(a[k], b[k]), k
+    assert bytes(acc_a) == bytes(acc_b)
+    # a second pass over the same samples only bumps counts
+    acc_c, st = engine.nsq_db_batch(seed, 0, n)
+    assert st.new_rows == 0 and st.rows == len(b["count"]) and acc_c.n == 2 * n and acc_c.n_fail == 2 * acc_b.n_fail
+    assert acc_c.sum_dns == pytest.approx(2 * acc_b.sum_dns, rel=1e-14)
+    # other solver options need a fresh database
+    with pytest.raises(api.RelmcError):
+        engine.nsq_db_batch(seed, 0, 100, api.mpoption(api.PHYSICAL))
+    engine.db_reset()
+    assert engine.db_size() == (0, 0)
+
+
+def test_state_database_run_to_convergence(engine, oracle):
+    """relmc_nsq_run(distinct_states = 2) to beta < 1 % and on to the reference's own limit beta < 0.0017 (about 7.3e6
+    samples): same stopping point and integer accumulators as the per-sample path; growth of the database across its
+    initial capacity (65 536 rows) is exercised on the way."""
+    for beta_limit, batch in ((0.01, 50_000), (0.0017, 500_000)):
+        a = engine.nsqMain(beta_limit=beta_limit, max_iterations=20_000_000, samples_per_batch=batch, seed=1)
+        b = engine.nsqMain(beta_limit=beta_limit, max_iterations=20_000_000, samples_per_batch=batch, seed=1, distinct_states="database")
+        assert a.converged and b.converged and a.current_iteration == b.current_iteration
+        ai, ad = a.acc.to_arrays(); bi, bd = b.acc.to_arrays()
+        assert np.array_equal(ai, bi)
+        np.testing.assert_allclose(bd, ad, rtol=1e-9, atol=1e-6)
+        np.testing.assert_allclose(b.beta_history, a.beta_history, rtol=1e-7)
+        assert b.database_row_count < 0.1 * b.current_iteration      # 6.6 % distinct at 2.5e5 samples, 1.7 % at 8e6
+    assert b.database_row_count > 65_536
+    rep = b.report()
+    assert "Unique states evaluated: %d" % b.database_row_count in rep and "Convergence achieved: YES" in rep
+    assert "Top 5 Critical Components" in rep and "Top 5 Buses by EENS" in rep

@@ -157,3 +157,35 @@ def test_gpu96_distinct_state_path(engine96):
     np.testing.assert_array_equal(ai, pi)
     np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
     assert 0 < nd <= n
+
+
+@pytest.mark.gpu
+def test_gpu96_state_database_matches_oracle(engine96, oracle96):
+    """The persistent unique-state database (nsqMain.m:220-278) on the wide tile (219-bit keys) against the oracle's
+    database-form restatement of the loop: same rows in the same order, counts, flags, dns; and against the per-sample path."""
+    from powersystemsreliabilityassessment_amd import api
+    n, batch, seed = 2400, 800, 6
+    r = engine96.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=batch, seed=seed, distinct_states="database")
+    db = engine96.db_export()
+    ref = oracle96.nsq_database(seed, 0.0, n, batch, nthreads=16, max_rows=n)
+    assert r.database_row_count == len(ref["count"]) == len(db["count"]) and db["count"].sum() == n
+    np.testing.assert_array_equal(db["states"], ref["states"])
+    np.testing.assert_array_equal(db["count"], ref["count"])
+    np.testing.assert_array_equal(db["flag"], ref["flag"])
+    np.testing.assert_array_equal(db["status"], ref["status"])
+    np.testing.assert_allclose(db["dns"], ref["dns"], rtol=0, atol=1e-5)
+    np.testing.assert_allclose(r.edns_history, ref["edns_history"], rtol=1e-8)
+    np.testing.assert_allclose(r.beta_history, ref["beta_history"], rtol=1e-6)
+    ai, ad = r.acc.to_arrays(); ri, rd = ref["acc"].to_arrays()
+    np.testing.assert_array_equal(ai[:5], ri[:5]); np.testing.assert_array_equal(ai[6:], ri[6:])
+    plain = engine96.nsq_accumulate(seed, 0, n)
+    pi, pd = plain.to_arrays()
+    np.testing.assert_array_equal(ai, pi)
+    np.testing.assert_allclose(ad, pd, rtol=1e-10, atol=1e-7)
+    # a larger run on the device only: database == per-sample path, integers exact
+    n2 = 300_000
+    b = engine96.nsqMain(beta_limit=0.0, max_iterations=n2, samples_per_batch=100_000, seed=2, distinct_states="database")
+    a = engine96.nsq_accumulate(2, 0, n2)
+    np.testing.assert_array_equal(b.acc.to_arrays()[0], a.to_arrays()[0])
+    np.testing.assert_allclose(b.acc.to_arrays()[1], a.to_arrays()[1], rtol=1e-10, atol=1e-6)
+    assert b.database_row_count > 65_536                   # grew past the initial capacity
