@@ -219,6 +219,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         for (int s = 0; s < LS; ++s) PA.cf_line[s] = 0;
         PA.n = 0; PA.nfail = 0; PA.nsing = 0; PA.ninf = 0; PA.nnc = 0; PA.iters = 0; PA.pad = 0;
     }
+    // the two counters every scenario touches stay in registers and reach the record once, at the end of the kernel: the
+    // record is then written only by scenarios that shed load (8.5 % on RTS-24) instead of by all of them
+    uint32_t acc_n = 0, acc_it = 0;
 
     PT_DECL
     const int64_t ngroups = (a.n + SPW - 1) / SPW;
@@ -1053,7 +1056,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             for (int s = 0; s < LS; ++s)
                 if (MODE != 4 && fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
             if (MODE != 4 && rlane == 0) {          // row-uniform quantities: one lane per scenario row
-                PA.n += wgt;
+                acc_n += wgt;
                 if (dns != 0.0) {
                     if (MODE == 3) { PA.dns = __builtin_fma((double)wgt, dns, PA.dns); PA.dns2 = __builtin_fma((double)wgt * dns, dns, PA.dns2); }
                     else { PA.dns += dns; PA.dns2 = __builtin_fma(dns, dns, PA.dns2); }
@@ -1062,7 +1065,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 if (status == 3) PA.nsing += wgt;
                 if (status == 1 || status == 2) PA.nnc += wgt;
                 if (infeas) PA.ninf += wgt;
-                PA.iters += (uint32_t)it * wgt;
+                acc_it += (uint32_t)it * wgt;
             }
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
             if (MODE == 1 || MODE == 4) {
@@ -1093,6 +1096,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         PT_MARK(7)
     }
     }
+    if (rlane == 0) { PA.n = acc_n; PA.iters = acc_it; }
     PT_FLUSH
 }
 
