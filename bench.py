@@ -7,9 +7,17 @@
 A "step" is one pass of the fused hot path (sample -> DC-OPF interior point -> accumulate) over one
 batch of `--batch` (default 1e6 = BASELINE.json configs[1]) synthetic scenarios PER GPU, followed
 by the convergence check's all-reduce of the index accumulators when N > 1 (weak scaling: the
-per-GPU batch is fixed).  Scenarios are generated in-kernel by the counter-based sampler, so there
-is no input to stage: the timed region starts with everything it needs resident in HBM (the case
-tables, ~5 KB).  Prints ONE JSON line on rank 0.
+per-GPU batch is fixed; `--scaling strong --total T` fixes the work per step instead: BASELINE configs[2]).
+Scenarios are generated in-kernel by the counter-based sampler, so there is no input to stage: the
+timed region starts with everything it needs resident in HBM (the case tables, ~5 KB).
+Prints ONE JSON line on rank 0.
+
+What the `roofline` object means here: the dominant kernel issues no MFMA; it is bound by the
+fp64 VALU pipe and the CU's LDS pipe together.  `achieved` / `frac` price the fp64 operations the kernel EXECUTES
+(static schedule of the sparse block LDL' + per-element work) against the fp64 vector peak, the same definition for
+every workload; `frac_dense_equiv` keeps SURVEY.md 8d's dense-equivalent count beside it.  Pipe utilisations and HBM
+traffic cannot be read by a program about itself: they come from the committed rocprofv3 PMC passes of this very
+command (profiles/<current>/pmc_summary.json) and say so in `counters_source`.
 """
 from __future__ import annotations
 
@@ -23,7 +31,13 @@ ROOT = os.path.dirname(os.path.abspath(__file__))
 sys.path.insert(0, ROOT)
 
 FP64_PEAK_TFLOPS = 78.6         # MI355X fp64 vector = matrix peak: 256 CU x 4 SIMD x 16 FMA/clk x 2 x 2.4 GHz
-FLOP_PER_ITER = 40.5e3          # algorithmic flops of one reduced (order 47) Newton step
+GPU_CLOCK_HZ = 2.4e9
+
+
+def dense_flop_per_iter(nb):
+    """algorithmic flops of one Newton step on the dense reduced system of order n_r = 2 nb - 1."""
+    n = 2 * nb - 1
+    return n ** 3 / 3.0 + 2.0 * n * n + 1.5e3
 
 
 def main():
@@ -31,22 +45,27 @@ def main():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=5)
     ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--batch", type=int, default=1_000_000, help="scenarios per GPU per step")
+    ap.add_argument("--batch", type=int, default=1_000_000, help="scenarios per GPU per step (weak scaling)")
+    ap.add_argument("--scaling", choices=["weak", "strong"], default="weak")
+    ap.add_argument("--total", type=int, default=100_000_000, help="strong scaling: scenarios per step over all GPUs (BASELINE configs[2]: 1e8)")
     ap.add_argument("--workload", choices=["nsq24", "rts96", "seq"], default="nsq24",
                     help="nsq24 = BASELINE configs[1] (the headline, default); rts96 = configs[4] shape; seq = configs[3] shape")
     ap.add_argument("--years", type=int, default=125, help="seq workload: simulated years per GPU per step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
+    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
+                    help="who all-reduces relmc_acc: torch.distributed (default) or the library's own RCCL communicator (relmc_comm_*)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--no-time-to-cov", action="store_true", help="skip the nsqMain run (profiling: only identical 1e6 launches)")
+    ap.add_argument("--no-time-to-cov", action="store_true", help="skip the nsqMain runs (profiling: only identical launches)")
     ap.add_argument("--cpu-sample", type=int, default=0, help="scenarios of the CPU baseline sample (0 = auto)")
+    ap.add_argument("--dump-acc", default="", help="testing: rank 0 writes the merged accumulators of the timed steps to this file")
     args = ap.parse_args()
 
     import torch
     import torch.distributed as dist
-    from powersystemsreliabilityassessment_amd import api, case24, dist as rdist
+    from powersystemsreliabilityassessment_amd import api, case24, case96, dist as rdist
 
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
@@ -66,136 +85,48 @@ def main():
         else:
             dist.init_process_group(args.backend, rank=rank, world_size=world)
 
-    if args.workload != "nsq24":
-        return secondary_workload(args, world, rank, local_rank, device)
-    case = case24.rts24()
-    eng = api.Engine(case, device=local_rank)
+    def sync():
+        if world > 1:
+            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
+        torch.cuda.synchronize()
+
     policy = api.REFERENCE_EMULATE if args.policy == "emulate" else api.PHYSICAL
     opts = api.mpoption(policy)
-    B = args.batch
-
-    def step(k):
-        # global scenario index space: step k, rank r owns [ (k*world + r)*B, +B )
-        acc = eng.nsq_accumulate(args.seed, (k * world + rank) * B, B, opts)
-        ms = eng.last_kernel_ms()
-        acc = rdist.allreduce_acc(acc, device)       # the convergence check's single all-reduce
-        return acc, ms
-
-    def sync():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize()
-
-    for k in range(args.warmup):
-        step(k)
-    sync()
-    t0 = time.perf_counter()
-    total = None
-    kernel_ms = []
-    for k in range(args.steps):
-        acc, ms = step(args.warmup + k)
-        kernel_ms.append(ms)
-        total = acc if total is None else rdist.merge(total, acc)
-    sync()
-    elapsed = time.perf_counter() - t0
-    if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
-        dist.all_reduce(t, op=dist.ReduceOp.MAX)
-        elapsed = float(t.item())
-
-    if rank == 0:
-        n_total = int(total.n)
-        idx = rdist.indices_from_acc(total, case.nb, case.ncomp)
-        value = n_total / elapsed
-        avg_kernel_s = sum(kernel_ms) / len(kernel_ms) * 1e-3
-        flop_per_scen = idx["mean_iters"] * FLOP_PER_ITER
-        achieved = B * flop_per_scen / avg_kernel_s / 1e12          # per GPU, dominant kernel
-        out = {
-            "metric": "Monte Carlo DC-OPF scenarios/sec (RTS-24 HL2 non-sequential)",
-            "value": value, "unit": "scenarios/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak",
-            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
-            "config": {"workload": "HL2 non-sequential MCS, IEEE RTS-24 DC-OPF load shedding, "
-                                   f"{B:d} samples per GPU per step (BASELINE configs[1])",
-                       "scenarios_per_step_per_gpu": B, "policy": args.policy, "seed": args.seed,
-                       "parallelism": f"scenario-index sharding x{world}, 1 all-reduce of relmc_acc per step"},
-            "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
-                         "frac": achieved / FP64_PEAK_TFLOPS, "traffic": hbm_traffic_from_profile(B),
-                         "kernel": "relmc_eval_kernel<0>", "kernel_ms_avg": avg_kernel_s * 1e3,
-                         "algorithmic_flop_per_scenario": flop_per_scen, "mean_ipm_iterations": idx["mean_iters"],
-                         "executed_flop_per_iteration_sparse_schedule": sparse_flop_per_iteration(eng, case)},
-            "indices": {"n": n_total, "edns_mw": idx["edns"], "lole_h_per_yr": idx["lole"], "plc": idx["plc"],
-                        "beta": idx["beta"], "n_singular": int(total.n_singular),
-                        "n_nonconverged": int(total.n_nonconverged)},
-        }
-        # wall-time to EENS CoV < 1 % (second half of BASELINE.json's metric), single GPU loop of nsqMain
-        if world == 1 and not args.no_time_to_cov:
-            t1 = time.perf_counter()
-            r = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000,
-                            seed=args.seed, mpopt=opts)
-            out["time_to_cov_1pct"] = {"seconds": time.perf_counter() - t1, "samples": r.current_iteration,
-                                       "beta": r.current_beta, "edns_mw": r.accumulated_edns,
-                                       "batch": 100_000, "converged": r.converged}
-        if world == 1 and not args.no_time_to_cov:
-            # the reference's own speed trick (nsqMain.m:220-245), reported beside the headline, never as `value`:
-            # distinct states of a batch solved once and weighted by multiplicity (sampling + device sort + evaluation)
-            eng.nsq_accumulate_distinct(args.seed, 0, B, opts)
-            t1 = time.perf_counter()
-            acc_d, nd = eng.nsq_accumulate_distinct(args.seed, 7 * B, B, opts)
-            dt = time.perf_counter() - t1
-            t1 = time.perf_counter()
-            r = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000, seed=args.seed, mpopt=opts, distinct_states=True)
-            out["distinct_state_path"] = {"samples_per_s": B / dt, "batch": B, "distinct_states": nd, "ms": dt * 1e3,
-                                          "time_to_cov_1pct_seconds": time.perf_counter() - t1, "samples": r.current_iteration, "beta": r.current_beta}
-        if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
-        print(json.dumps(out), flush=True)
-    if world > 1:
-        dist.destroy_process_group()
-
-
-def sparse_flop_per_iteration(eng, case):
-    """Floating-point operations one Newton iteration of the shipped sparse solver executes per scenario: the static
-    schedule's task counts (43 flop per 2x2 block update, 29 per right-hand-side update, 21 per pivot inversion, 14 per
-    back-substitution task) plus the per-element work on lines, injections and buses (about 60 / 70 / 30 flop each)."""
-    import ctypes as C
-    out = (C.c_int32 * 9)()
-    eng.L.relmc_debug_schedule(eng._h, out)
-    noff, ntask = out[3], out[8]
-    nblock = ntask - case.nb - 2 * noff
-    return 43.0 * nblock + 29.0 * noff + 21.0 * case.nb + 14.0 * noff + 60.0 * case.nl + 70.0 * case.ninj + 30.0 * case.nb
-
-
-def secondary_workload(args, world, rank, local_rank, device):
-    """The two other GPU configurations of BASELINE.json, same timing contract, one JSON line:
-       rts96: non-sequential MCS on the 73-bus RTS-96 (one scenario per wavefront tile), --batch scenarios per GPU per step;
-       seq:   sequential MCS on RTS-24, --years simulated years per GPU per step (8736 hourly states each, only the
-              contingency hours are evaluated, seqMain.m:97), annual indices all-gathered per step."""
-    import numpy as np
-    import torch
-    import torch.distributed as dist
-    from powersystemsreliabilityassessment_amd import api, case24, case96, dist as rdist, seq as rseq
-
-    def sync():
-        if world > 1:
-            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
-        torch.cuda.synchronize()
-
+    sq = None
     if args.workload == "rts96":
         case = case96.rts96()
-        eng = api.Engine(case, device=local_rank)
-        B = args.batch
-        opts = api.mpoption(api.REFERENCE_EMULATE)
-
-        def step(k):
-            acc = eng.nsq_accumulate(args.seed, (k * world + rank) * B, B, opts)
-            ms = eng.last_kernel_ms()
-            return rdist.allreduce_acc(acc, device), ms, B
-        unit, metric = "scenarios/s", "Monte Carlo DC-OPF scenarios/sec (RTS-96 HL2 non-sequential)"
-        workload = f"HL2 non-sequential MCS, IEEE RTS-96 (73 buses, 120 branches, 99 generator rows) DC-OPF load shedding, {B} samples per GPU per step (BASELINE configs[4] shape)"
     else:
         case = case24.rts24()
-        eng = api.Engine(case, device=local_rank)
+    eng = api.Engine(case, device=local_rank)
+    comm = None
+    if world > 1 and args.comm == "native":
+        comm = rdist.NativeComm(eng, rank, world)           # RCCL through the C ABI; the unique id travels over the torch store
+
+    def allreduce(acc):
+        return comm.allreduce_acc(acc) if comm is not None else rdist.allreduce_acc(acc, device)
+
+    B = args.batch
+    if args.workload in ("nsq24", "rts96"):
+        def step(k):
+            if args.scaling == "strong":
+                lo, cnt = rdist.shard_range(k * args.total, args.total, rank, world)
+            else:
+                lo, cnt = (k * world + rank) * B, B        # global scenario index space: step k, rank r owns [(k*world + r)*B, +B)
+            acc = eng.nsq_accumulate(args.seed, lo, cnt, opts)
+            ms = eng.last_kernel_ms()
+            return allreduce(acc), ms, cnt                 # the convergence check's single all-reduce
+        unit = "scenarios/s"
+        if args.workload == "nsq24":
+            metric = "Monte Carlo DC-OPF scenarios/sec (RTS-24 HL2 non-sequential)"
+            per = f"{B:d} samples per GPU per step (BASELINE configs[1])" if args.scaling == "weak" else f"{args.total:d} samples per step over all GPUs (BASELINE configs[2])"
+            workload = "HL2 non-sequential MCS, IEEE RTS-24 DC-OPF load shedding, " + per
+        else:
+            metric = "Monte Carlo DC-OPF scenarios/sec (RTS-96 HL2 non-sequential)"
+            workload = (f"HL2 non-sequential MCS, IEEE RTS-96 (73 buses, 120 branches, 99 generator rows) DC-OPF load shedding, "
+                        f"{B if args.scaling == 'weak' else args.total} samples per {'GPU per ' if args.scaling == 'weak' else ''}step (BASELINE configs[4] shape)")
+    else:
+        import numpy as np
+        from powersystemsreliabilityassessment_amd import seq as rseq
         sq = rseq.SeqEngine(eng)
         Y = args.years
 
@@ -203,7 +134,7 @@ def secondary_workload(args, world, rank, local_rank, device):
             e, d, n_, ncont, acc = sq.seq_years(args.seed, (k * world + rank) * Y, Y)
             ms = eng.last_kernel_ms()
             rdist.allgather_years(np.column_stack([e, d, n_]), [Y] * world, device)
-            return rdist.allreduce_acc(acc, device), ms, int(acc.n)
+            return allreduce(acc), ms, int(acc.n)
         unit, metric = "hourly DC-OPFs/s", "Monte Carlo hourly DC-OPF evaluations/sec (RTS-24 HL2 sequential)"
         workload = f"HL2 sequential MCS, RTS-24, {Y} simulated years x 8736 h per GPU per step, contingency hours only (BASELINE configs[3] shape)"
 
@@ -222,40 +153,138 @@ def secondary_workload(args, world, rank, local_rank, device):
         t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+
+    # wall-time to EENS CoV < 1 % over all ranks (second half of BASELINE.json's metric), outside the timed region
+    ttc_multi = None
+    if world > 1 and args.workload == "nsq24" and not args.no_time_to_cov:
+        sync()
+        t1 = time.perf_counter()
+        idx, tot, hist = rdist.nsq_run_distributed(lambda s, lo, n: eng.nsq_accumulate(s, lo, n, opts), case.nb, case.ncomp, seed=args.seed,
+                                                   beta_limit=0.01, max_samples=50_000_000, batch=100_000 * world, device=device,
+                                                   allreduce=allreduce)
+        sync()
+        ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": 100_000 * world}
+
     if rank == 0:
         n_total = int(total.n)
         mean_iters = total.sum_iters / n_total
-        fl = sparse_flop_per_iteration(eng, case)
         avg_kernel_s = sum(kernel_ms) / len(kernel_ms) * 1e-3
-        achieved = (units_rank / args.steps) * mean_iters * fl / avg_kernel_s / 1e12
-        out = {"metric": metric, "value": n_total / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
-               "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-               "dtype": "f64", "data": "synthetic",
-               "config": {"workload": workload, "seed": args.seed, "parallelism": f"index / year sharding x{world}, accumulators all-reduced per step"},
-               "roofline": {"bound": "mfma", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s", "frac": achieved / FP64_PEAK_TFLOPS,
-                            "traffic": None, "kernel": "relmc_eval_kernel", "kernel_ms_avg": avg_kernel_s * 1e3,
-                            "flop_model": "operations of the sparse block LDL' schedule + per-element work (bench.sparse_flop_per_iteration); "
-                                          "SURVEY 8d's dense count would exceed the peak on this workload",
-                            "flop_per_iteration": fl, "mean_ipm_iterations": mean_iters},
-               "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "loss_fraction": total.n_fail / n_total,
-                           "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged)}}
+        units_per_launch = units_rank / args.steps                      # what ONE launch of the dominant kernel processes on this rank
+        fl_exec = sparse_flop_per_iteration(eng, case)
+        fl_dense = dense_flop_per_iter(case.nb)
+        achieved = units_per_launch * mean_iters * fl_exec / avg_kernel_s / 1e12
+        achieved_dense = units_per_launch * mean_iters * fl_dense / avg_kernel_s / 1e12
+        kname = "relmc_eval_kernel<2>" if args.workload == "seq" else "relmc_eval_kernel<0>"
+        roof = {"bound": "fp64-valu+lds-pipe (no MFMA issued)", "achieved": achieved, "peak": FP64_PEAK_TFLOPS, "unit": "TFLOP/s",
+                "frac": achieved / FP64_PEAK_TFLOPS, "frac_executed": achieved / FP64_PEAK_TFLOPS,
+                "frac_dense_equiv": achieved_dense / FP64_PEAK_TFLOPS,
+                "flop_model": "achieved/frac = fp64 operations the kernel executes per Newton step (static sparse block-LDL' schedule + per-element work, "
+                              "bench.sparse_flop_per_iteration) x measured mean IPM iterations; frac_dense_equiv = SURVEY 8d's dense reduced order-(2nb-1) count "
+                              "(above 1 on RTS-96: that count is avoidable work)",
+                "flop_per_iteration_executed": fl_exec, "flop_per_iteration_dense_equiv": fl_dense, "mean_ipm_iterations": mean_iters,
+                "kernel": kname, "kernel_ms_avg": avg_kernel_s * 1e3, "units_per_launch": units_per_launch}
+        roof.update(counters_from_profile(args.workload, units_per_launch, torch.cuda.get_device_properties(local_rank).multi_processor_count))
+        out = {
+            "metric": metric, "value": n_total / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+            "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
+            "vs_baseline": None, "dtype": "f64", "data": "synthetic",
+            "config": {"workload": workload, "policy": args.policy, "seed": args.seed,
+                       "parallelism": f"scenario-index{' / year' if args.workload == 'seq' else ''} sharding x{world}, 1 all-reduce of relmc_acc per step "
+                                      f"({'RCCL through the C ABI' if comm is not None else 'torch.distributed ' + (args.backend if world > 1 else '(single rank: no collective)')})"},
+            "roofline": roof,
+            "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "plc": total.n_fail / n_total,
+                        "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged)},
+        }
+        if args.workload == "nsq24":
+            idx = rdist.indices_from_acc(total, case.nb, case.ncomp)
+            out["indices"].update({"lole_h_per_yr": idx["lole"], "beta": idx["beta"]})
+        if ttc_multi is not None:
+            out["time_to_cov_1pct"] = ttc_multi
+        if world == 1 and args.workload == "nsq24" and not args.no_time_to_cov:
+            t1 = time.perf_counter()
+            r = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000, seed=args.seed, mpopt=opts)
+            out["time_to_cov_1pct"] = {"seconds": time.perf_counter() - t1, "samples": r.current_iteration, "beta": r.current_beta,
+                                       "edns_mw": r.accumulated_edns, "batch": 100_000, "converged": r.converged}
+            # the reference's own speed trick (nsqMain.m:220-278), reported beside the headline, never as `value`: the persistent
+            # unique-state database on the device (known states bump a count, only new states are solved)
+            eng.db_reset(); eng.nsq_db_batch(args.seed, 0, B, opts); eng.db_reset()                   # warm-up: allocations
+            rates = []
+            for k in range(4):
+                t1 = time.perf_counter(); _, st = eng.nsq_db_batch(args.seed, k * B, B, opts); dt = time.perf_counter() - t1
+                rates.append({"batch": k, "ms": dt * 1e3, "samples_per_s": B / dt, "rows": int(st.rows), "new_rows": int(st.new_rows)})
+            t1 = time.perf_counter()
+            r1 = eng.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000, seed=args.seed, mpopt=opts, distinct_states="database")
+            dt1 = time.perf_counter() - t1
+            t1 = time.perf_counter()
+            r2 = eng.nsqMain(beta_limit=0.0017, max_iterations=50_000_000, samples_per_batch=1_000_000, seed=args.seed, mpopt=opts, distinct_states="database")
+            dt2 = time.perf_counter() - t1
+            out["distinct_state_path"] = {
+                "what": "persistent unique-state database on the device (relmc_nsq_db_batch), 1e6-sample batches from an empty database",
+                "batches": rates,
+                "time_to_cov_1pct_seconds": dt1, "samples": r1.current_iteration, "beta": r1.current_beta, "rows": r1.database_row_count,
+                "time_to_reference_beta_limit_0.0017": {"seconds": dt2, "samples": r2.current_iteration, "beta": r2.current_beta,
+                                                        "rows": r2.database_row_count, "edns_mw": r2.accumulated_edns}}
+        if world == 1 and not args.no_cpu_baseline and args.workload == "nsq24":
+            out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
+        if args.dump_acc:
+            ints, dbls = total.to_arrays()
+            with open(args.dump_acc, "w") as fh:
+                json.dump({"ints": ints.tolist(), "dbls": [float(x).hex() for x in dbls]}, fh)
         print(json.dumps(out), flush=True)
+    if comm is not None:
+        comm.close()
     if world > 1:
         dist.destroy_process_group()
 
 
-def hbm_traffic_from_profile(batch):
-    """HBM bytes per launch of the dominant kernel, from the committed rocprofv3 PMC passes of the profile named in
-    profiles/current.txt (pmc_summary.json: FETCH_SIZE and WRITE_SIZE collected in separate runs of this command, gfx950
-    correction applied); scaled to this batch.  None if no profile is committed."""
+def sparse_flop_per_iteration(eng, case):
+    """Floating-point operations one Newton iteration of the shipped sparse solver executes per scenario: the static
+    schedule's task counts (43 flop per 2x2 block update, 29 per right-hand-side update, 21 per pivot inversion, 14 per
+    back-substitution task) plus the per-element work on lines, injections and buses (about 60 / 70 / 30 flop each)."""
+    import ctypes as C
+    out = (C.c_int32 * 9)()
+    eng.L.relmc_debug_schedule(eng._h, out)
+    noff, ntask = out[3], out[8]
+    nblock = ntask - case.nb - 2 * noff
+    return 43.0 * nblock + 29.0 * noff + 21.0 * case.nb + 14.0 * noff + 60.0 * case.nl + 70.0 * case.ninj + 30.0 * case.nb
+
+
+def counters_from_profile(workload, units_per_launch, n_cu):
+    """Pipe utilisations and HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this command
+    (profiles/<current>/pmc_summary[_<workload>].json; separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
+    SQ cycle counters tick once per 4 clocks per wavefront; GRBM_GUI_ACTIVE sums the 8 XCDs."""
+    none = {"traffic": None, "lds_pipe_busy": None, "lds_conflict_frac": None, "valu_busy": None, "waves_per_simd": None,
+            "mfma_fp64_ops": None, "counters_source": "no committed profile for this workload"}
     try:
         with open(os.path.join(ROOT, "profiles", "current.txt")) as fh:
             name = fh.read().strip()
-        with open(os.path.join(ROOT, "profiles", name, "pmc_summary.json")) as fh:
-            t = json.load(fh).get("hbm_traffic")
-        return t["bytes_per_scenario"] * batch if t else None
-    except (OSError, ValueError, KeyError):
-        return None
+        fn = "pmc_summary.json" if workload == "nsq24" else f"pmc_summary_{workload}.json"
+        with open(os.path.join(ROOT, "profiles", name, fn)) as fh:
+            summ = json.load(fh)
+    except (OSError, ValueError):
+        return none
+    ev = [k for k in summ if "eval_kernel" in k]
+    if not ev:
+        return none
+    k = summ[ev[0]]
+    try:
+        sq, lds = k["pmc_sq"]["sums"], k["pmc_lds"]["sums"]
+        n_disp = max(1, k["pmc_lds"]["dispatches"])
+        cyc = lds["GRBM_GUI_ACTIVE"] / 8.0                                  # kernel-active clocks of the profiled launches (summed over them)
+        res = {"lds_pipe_busy": lds["SQ_LDS_IDX_ACTIVE"] / (n_cu * cyc),
+               "lds_conflict_frac": lds["SQ_LDS_BANK_CONFLICT"] / lds["SQ_LDS_IDX_ACTIVE"],
+               "valu_busy": 4.0 * sq["SQ_ACTIVE_INST_VALU"] / (4.0 * n_cu * cyc),
+               "waves_per_simd": lds["SQ_WAVES"] / n_disp / (4.0 * n_cu),      # resident wavefronts: the persistent grid fills the device once
+               "mfma_fp64_ops": lds.get("SQ_INSTS_VALU_MFMA_MOPS_F64"),
+               "lds_instructions_per_unit": sq["SQ_INSTS_LDS"] / summ.get("units_per_profiled_launch", units_per_launch) / max(1, k["pmc_sq"]["dispatches"]),
+               "valu_instructions_per_unit": sq["SQ_INSTS_VALU"] / summ.get("units_per_profiled_launch", units_per_launch) / max(1, k["pmc_sq"]["dispatches"])}
+        t = summ.get("hbm_traffic")
+        res["traffic"] = t["bytes_per_scenario"] * units_per_launch if t else None
+        res["traffic_unit"] = "bytes per launch (HBM, PMC FETCH_SIZE x2 + WRITE_SIZE)"
+        res["counters_source"] = f"from_profile: profiles/{name}/{fn} (rocprofv3 --pmc passes of `bench.py --workload {workload} --steps 1 --warmup 0`, not measured in this run)"
+        return res
+    except (KeyError, ZeroDivisionError, TypeError):
+        return none
 
 
 def cpu_baseline(case, policy, seed, n_sample):
@@ -276,7 +305,7 @@ def cpu_baseline(case, policy, seed, n_sample):
     t0 = time.perf_counter()
     orc.nsq_accumulate(seed, 0, 200 * cores, policy, nthreads=cores, memo=False)     # calibration
     rate = 200 * cores / (time.perf_counter() - t0)
-    n = n_sample or int(max(2000, min(2_000_000, rate * 15.0)))                      # ~15 s of CPU work
+    n = n_sample or int(max(2000, min(2_000_000, rate * 12.0)))                      # ~12 s of CPU work
     t0 = time.perf_counter()
     acc = orc.nsq_accumulate(seed, 0, n, policy, nthreads=cores, memo=False)
     dt = time.perf_counter() - t0
@@ -284,10 +313,19 @@ def cpu_baseline(case, policy, seed, n_sample):
     n1 = 1500
     orc.nsq_accumulate(seed, 0, n1, policy, nthreads=1, memo=False)                  # single-core figure as well
     dt1 = time.perf_counter() - t1
+    # wall-time to EENS CoV < 1 % on the CPU: the reference's own algorithm — the nsqMain loop with its
+    # unique-state database, batches of 100 as nsqMain.m:62 — restated in C, new states evaluated on all granted cores
+    t2 = time.perf_counter()
+    d = orc.nsq_database(seed, 0.01, 5_000_000, 100, policy=policy, nthreads=cores, max_rows=200_000)
+    dt2 = time.perf_counter() - t2
     return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port", "single_core_value": n1 / dt1, "cpu_quota": quota,
             "sample": f"first {n} scenarios of the same seed, every scenario solved (no state memo), "
                       f"{dt:.1f} s on {cores} OpenMP threads (host CPUs visible {os.cpu_count()}, cgroup quota {quota})",
-            "edns_mw": acc.sum_dns / acc.n}
+            "edns_mw": acc.sum_dns / acc.n,
+            "time_to_cov_1pct": {"seconds": dt2, "samples": d["iterations"], "beta": float(d["beta_history"][-1]), "unique_states_solved": int(len(d["count"])),
+                                 "edns_mw": float(d["edns_history"][-1]),
+                                 "how": "nsqMain loop in the reference's database form (oracle orc_nsq_database, batches of 100, only new states solved), "
+                                        f"{cores} threads; solving every sample instead would take samples / value = {d['iterations'] / (n / dt):.1f} s"}}
 
 
 if __name__ == "__main__":

@@ -227,6 +227,19 @@ int32_t relmc_db_size(const relmc_ctx* ctx, int64_t* rows_out, int64_t* samples_
 int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8_t* states_host, int64_t* count_host,
                         double* dns_host, int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host);
 
+/* ---- multi-GPU: the path's single collective (the reference's parfor, nsqMain.m:257-263) ------------ */
+/* One process per GPU, one context per process.  Scenarios shard by global index (any contiguous split of
+ * [first_index, first_index + n) over the ranks); at a convergence check every rank calls relmc_comm_allreduce_acc on the
+ * accumulators of its slice: ONE grouped RCCL all-reduce(sum) over xGMI (int64 counters and fp64 sums in their own types).
+ * The communicator is bootstrapped like any RCCL communicator: rank 0 calls relmc_comm_unique_id and hands the 128 bytes
+ * to the other ranks by the host's own means (file, socket, MPI, Julia Distributed, torch store), then every rank calls
+ * relmc_comm_init.  RCCL is bound at run time (dlopen): hosts that never call these need no RCCL installed. */
+#define RELMC_COMM_ID_BYTES 128
+int32_t relmc_comm_unique_id(uint8_t id_out[RELMC_COMM_ID_BYTES]);
+int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint8_t id[RELMC_COMM_ID_BYTES]);
+int32_t relmc_comm_allreduce_acc(relmc_ctx* ctx, relmc_acc* acc_inout);
+int32_t relmc_comm_destroy(relmc_ctx* ctx);
+
 /* ---- estimators (host arithmetic, no device) ---------------------------------------- */
 void relmc_acc_zero(relmc_acc* acc);
 void relmc_acc_merge(relmc_acc* dst, const relmc_acc* src);

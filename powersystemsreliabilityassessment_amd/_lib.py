@@ -23,6 +23,7 @@ EXPORTS = [
     "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate", "relmc_nsq_accumulate_distinct",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
+    "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy",
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years",
 ]
@@ -101,6 +102,14 @@ def load():
     L.relmc_nsq_indices.restype = None
     L.relmc_nsq_run.argtypes = [vp, C.POINTER(_abi.NsqOpts), C.POINTER(_abi.NsqResult)]
     L.relmc_nsq_run.restype = C.c_int32
+    L.relmc_comm_unique_id.argtypes = [u8p]
+    L.relmc_comm_unique_id.restype = C.c_int32
+    L.relmc_comm_init.argtypes = [vp, C.c_int32, C.c_int32, u8p]
+    L.relmc_comm_init.restype = C.c_int32
+    L.relmc_comm_allreduce_acc.argtypes = [vp, C.POINTER(_abi.Acc)]
+    L.relmc_comm_allreduce_acc.restype = C.c_int32
+    L.relmc_comm_destroy.argtypes = [vp]
+    L.relmc_comm_destroy.restype = C.c_int32
     L.relmc_db_reset.argtypes = [vp]
     L.relmc_db_reset.restype = C.c_int32
     L.relmc_nsq_db_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts), C.POINTER(_abi.Acc),

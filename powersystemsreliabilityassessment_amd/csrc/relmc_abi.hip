@@ -14,6 +14,8 @@
 #include <algorithm>
 #include <cstddef>
 
+#include <dlfcn.h>
+
 #include <rocprim/rocprim.hpp>
 
 #include "../../include/relmc.h"
@@ -49,6 +51,8 @@ struct relmc_ctx {
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
     double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
     bool db_has_opts = false; relmc_solver_opts db_opts;
+    // RCCL communicator over the ranks of a multi-GPU run (optional; relmc_comm_*)
+    void* comm = nullptr; int comm_nranks = 0, comm_rank = -1;
     // sequential track
     bool has_seq = false; SeqCase hseq; SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
@@ -62,6 +66,7 @@ namespace {
 
 const char* kNoCtx = "relmc: null context";
 void db_free(relmc_ctx* ctx);
+void comm_free(relmc_ctx* ctx);
 
 int fail(relmc_ctx* ctx, int code, const std::string& msg)
 {
@@ -545,7 +550,7 @@ int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
         hipMalloc(&ctx->dcase, sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess) {
-        delete ctx;
+        relmc_ctx_destroy(ctx);          // releases whatever was created before the failure
         return RELMC_ERR_NO_DEVICE;
     }
     ctx->num_cu = prop.multiProcessorCount;
@@ -569,6 +574,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dsorted) (void)hipFree(ctx->dsorted);
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
+    comm_free(ctx);
     db_free(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -1369,6 +1375,109 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     res->kernel_seconds = kernel_ms * 1e-3;
     res->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
     ctx->last_kernel_ms = kernel_ms;
+    return RELMC_OK;
+}
+
+// ---- multi-GPU: the one collective of the path, without any host framework -------------------------
+// RCCL is bound at run time (dlopen) so that the library has no link-time dependency on it and shares the copy a host
+// such as PyTorch may already have loaded.  ncclUniqueId is a 128-byte opaque struct; enums per rccl.h.
+namespace {
+struct RcclUid { char internal[128]; };
+struct RcclApi {
+    void* h = nullptr;
+    int (*GetUniqueId)(RcclUid*) = nullptr;
+    int (*CommInitRank)(void**, int, RcclUid, int) = nullptr;
+    int (*AllReduce)(const void*, void*, size_t, int, int, void*, hipStream_t) = nullptr;
+    int (*CommDestroy)(void*) = nullptr;
+    int (*GroupStart)() = nullptr;
+    int (*GroupEnd)() = nullptr;
+    const char* (*GetErrorString)(int) = nullptr;
+};
+RcclApi g_rccl;
+const char* rccl_load()
+{
+    if (g_rccl.h) return nullptr;
+    for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
+        g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
+        if (g_rccl.h) break;
+    }
+    if (!g_rccl.h) return "relmc_comm: librccl.so not found";
+    g_rccl.GetUniqueId = reinterpret_cast<int (*)(RcclUid*)>(dlsym(g_rccl.h, "ncclGetUniqueId"));
+    g_rccl.CommInitRank = reinterpret_cast<int (*)(void**, int, RcclUid, int)>(dlsym(g_rccl.h, "ncclCommInitRank"));
+    g_rccl.AllReduce = reinterpret_cast<int (*)(const void*, void*, size_t, int, int, void*, hipStream_t)>(dlsym(g_rccl.h, "ncclAllReduce"));
+    g_rccl.CommDestroy = reinterpret_cast<int (*)(void*)>(dlsym(g_rccl.h, "ncclCommDestroy"));
+    g_rccl.GroupStart = reinterpret_cast<int (*)()>(dlsym(g_rccl.h, "ncclGroupStart"));
+    g_rccl.GroupEnd = reinterpret_cast<int (*)()>(dlsym(g_rccl.h, "ncclGroupEnd"));
+    g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(g_rccl.h, "ncclGetErrorString"));
+    if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
+        g_rccl.h = nullptr;
+        return "relmc_comm: librccl.so lacks the expected entry points";
+    }
+    return nullptr;
+}
+void comm_free(relmc_ctx* ctx)
+{
+    if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
+    ctx->comm = nullptr;
+}
+int rccl_fail(relmc_ctx* ctx, const char* what, int rc)
+{
+    return fail(ctx, RELMC_ERR_HIP, std::string(what) + ": " + (g_rccl.GetErrorString ? g_rccl.GetErrorString(rc) : "RCCL error"));
+}
+}  // namespace
+
+int32_t relmc_comm_unique_id(uint8_t id_out[RELMC_COMM_ID_BYTES])
+{
+    if (!id_out) return RELMC_ERR_INVALID;
+    if (rccl_load()) return RELMC_ERR_UNSUPPORTED;
+    RcclUid u;
+    if (g_rccl.GetUniqueId(&u) != 0) return RELMC_ERR_HIP;
+    std::memcpy(id_out, u.internal, RELMC_COMM_ID_BYTES);
+    return RELMC_OK;
+}
+
+int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint8_t id[RELMC_COMM_ID_BYTES])
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_init: bad arguments");
+    if (ctx->comm) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_init: the context already has a communicator");
+    if (const char* e = rccl_load()) return fail(ctx, RELMC_ERR_UNSUPPORTED, e);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    RcclUid u;
+    std::memcpy(u.internal, id, RELMC_COMM_ID_BYTES);
+    void* comm = nullptr;
+    const int rc = g_rccl.CommInitRank(&comm, nranks, u, rank);
+    if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
+    ctx->comm = comm; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
+    return RELMC_OK;
+}
+
+// nsqMain.m:257-263's parfor gathers its slices implicitly; here: ONE grouped all-reduce(sum) over xGMI of the additive
+// accumulators, int64 counters and fp64 sums each in their own type (exact integers)
+int32_t relmc_comm_allreduce_acc(relmc_ctx* ctx, relmc_acc* acc)
+{
+    if (!ctx || !acc) return RELMC_ERR_INVALID;
+    if (!ctx->comm) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_allreduce_acc: relmc_comm_init has not been called");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->dacc, acc, sizeof(*acc), hipMemcpyHostToDevice, ctx->stream));
+    constexpr size_t NI = 6 + RELMC_MAX_COMP, ND = 2 + RELMC_MAX_BUS;
+    long long* di = reinterpret_cast<long long*>(ctx->dacc);
+    double* dd = reinterpret_cast<double*>(di + NI);
+    int rc = g_rccl.GroupStart();
+    if (rc == 0) rc = g_rccl.AllReduce(di, di, NI, /*ncclInt64*/ 4, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    if (rc == 0) rc = g_rccl.AllReduce(dd, dd, ND, /*ncclFloat64*/ 8, /*ncclSum*/ 0, ctx->comm, ctx->stream);
+    const int rc2 = g_rccl.GroupEnd();
+    if (rc != 0 || rc2 != 0) return rccl_fail(ctx, "ncclAllReduce", rc ? rc : rc2);
+    HIP_TRY(ctx, hipMemcpyAsync(acc, ctx->dacc, sizeof(*acc), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    return RELMC_OK;
+}
+
+int32_t relmc_comm_destroy(relmc_ctx* ctx)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (ctx->comm && g_rccl.CommDestroy) { (void)hipSetDevice(ctx->device); (void)g_rccl.CommDestroy(ctx->comm); }
+    ctx->comm = nullptr; ctx->comm_nranks = 0; ctx->comm_rank = -1;
     return RELMC_OK;
 }
 

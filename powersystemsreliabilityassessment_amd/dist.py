@@ -29,19 +29,49 @@ def allreduce_acc(acc: _abi.Acc, device=None) -> _abi.Acc:
     if not (dist.is_available() and dist.is_initialized()) or dist.get_world_size() == 1:
         return acc
     ints, dbls = acc.to_arrays()
-    world = dist.get_world_size()
     on_gpu = dist.get_backend() == "nccl"
     dev = (device if device is not None else torch.device("cuda", torch.cuda.current_device())) if on_gpu else None
-    # ONE collective: the int64 counters ride along as fp64, exact below 2^53 also after the sum over the ranks (a launch
-    # counts at most 2^31 scenarios x ~20 iterations; the branch-free form keeps every rank in the same collective)
-    if int(np.abs(ints).max(initial=0)) >= (1 << 52) // max(world, 1):
-        raise OverflowError("relmc_acc counter too large to all-reduce as fp64; reduce per launch, not the running total")
-    buf = torch.from_numpy(np.concatenate([ints.astype(np.float64), dbls]))
+    # ONE collective, unconditionally (no rank-local check may keep a rank out of it): every int64 counter rides along as
+    # two fp64 words (low / high 32 bits), each exact in fp64 also after the sum over up to 2^20 ranks
+    u = ints.astype(np.uint64)
+    lo = (u & np.uint64(0xffffffff)).astype(np.float64)
+    hi = (u >> np.uint64(32)).astype(np.float64)
+    buf = torch.from_numpy(np.concatenate([lo, hi, dbls]))
     if on_gpu:
         buf = buf.to(dev)
     dist.all_reduce(buf, op=dist.ReduceOp.SUM)
     out = buf.cpu().numpy()
-    return _abi.Acc.from_arrays(np.rint(out[:ints.size]).astype(np.int64), out[ints.size:])
+    n = ints.size
+    tot = [int(round(h)) * (1 << 32) + int(round(l)) for l, h in zip(out[:n], out[n:2 * n])]
+    if max(tot, default=0) >= (1 << 63):
+        raise OverflowError("relmc_acc counter exceeds int64 after the all-reduce")       # same on every rank: raised together
+    return _abi.Acc.from_arrays(np.array(tot, dtype=np.int64), out[2 * n:])
+
+
+class NativeComm:
+    """The library's own RCCL communicator (relmc_comm_*, include/relmc.h): what a Julia / C host would use.  Only the
+    128-byte unique id is exchanged through the host framework (here: torch.distributed's object broadcast)."""
+
+    def __init__(self, engine, rank: int, world: int):
+        import ctypes as C
+        import torch.distributed as dist
+        self.eng, self.rank, self.world = engine, rank, world
+        uid = (C.c_uint8 * 128)()
+        if rank == 0:
+            engine._check(engine.L.relmc_comm_unique_id(uid), "relmc_comm_unique_id")
+        box = [bytes(uid)]
+        dist.broadcast_object_list(box, src=0)
+        uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        engine._check(engine.L.relmc_comm_init(engine._h, world, rank, uid), "relmc_comm_init")
+
+    def allreduce_acc(self, acc: _abi.Acc) -> _abi.Acc:
+        import ctypes as C
+        out = _abi.Acc.from_buffer_copy(bytes(acc))
+        self.eng._check(self.eng.L.relmc_comm_allreduce_acc(self.eng._h, C.byref(out)), "relmc_comm_allreduce_acc")
+        return out
+
+    def close(self):
+        self.eng.L.relmc_comm_destroy(self.eng._h)
 
 
 def merge(a: _abi.Acc, b: _abi.Acc) -> _abi.Acc:
@@ -66,7 +96,7 @@ def indices_from_acc(acc: _abi.Acc, nb: int, ncomp: int, hours_per_year: float =
 
 def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, beta_limit: float = 0.0017,
                         max_samples: int = 100000, batch: int = 100, hours_per_year: float = 8760.0,
-                        rank: int | None = None, world: int | None = None, device=None):
+                        rank: int | None = None, world: int | None = None, device=None, allreduce=None):
     """The nsqMain loop (nsqMain.m:208-318) over `world` ranks.
 
     accumulate_fn(seed, first_index, n) -> _abi.Acc evaluates a scenario range on THIS rank
@@ -85,7 +115,7 @@ def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, be
         m = min(batch, max_samples - done)
         lo, cnt = shard_range(done, m, rank, world)
         part = accumulate_fn(seed, lo, cnt) if cnt > 0 else _abi.Acc()
-        part = allreduce_acc(part, device)
+        part = allreduce(part) if allreduce is not None else allreduce_acc(part, device)
         total = merge(total, part)
         done += m
         idx = indices_from_acc(total, nb, ncomp, hours_per_year)

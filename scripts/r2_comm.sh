@@ -1,0 +1,25 @@
+#!/bin/bash
+R=${GRAFT_REPO_ROOT:-$(pwd)}; cd $R
+python - <<PY
+import subprocess, time, os, sys, numpy as np
+sys.path.insert(0, "$R")
+from powersystemsreliabilityassessment_amd import case24
+import tests.test_c_abi as t
+import pathlib, tempfile
+d = pathlib.Path(tempfile.mkdtemp())
+exe = t._build_client(d)
+case = case24.rts24()
+f = d / "case.bin"
+with open(f, "wb") as fh:
+    fh.write(np.array([case.nb, case.ng, case.nl, case.nd, case.ref_bus], dtype=np.int32).tobytes())
+    fh.write(np.array([case.base_mva, case.total_load], dtype=np.float64).tobytes())
+    for a, ty in ((case.bus_pd, np.float64), (case.inj_bus, np.int32), (case.inj_pmin, np.float64), (case.inj_pmax, np.float64),
+                 (case.inj_cost, np.float64), (case.br_from, np.int32), (case.br_to, np.int32), (case.br_b, np.float64),
+                 (case.br_rate, np.float64), (case.unavail, np.float64), (case.always_up, np.uint8)):
+        fh.write(np.ascontiguousarray(a, dtype=ty).tobytes())
+t0 = time.time()
+out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=600)
+print("rc", out.returncode, "seconds", time.time() - t0)
+print("STDOUT:", out.stdout[-1500:])
+print("STDERR:", out.stderr[-1500:])
+PY

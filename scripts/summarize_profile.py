@@ -1,17 +1,20 @@
 #!/usr/bin/env python3
-"""Turns the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>/) into the committed summary
-profiles/<name>/{kernel_stats.csv, pmc_summary.json, bench_line.json}:   python scripts/summarize_profile.py <tag> <name>"""
+"""Turns the raw rocprofv3 output of scripts/profile.sh (gpurun_out/prof_<tag>_<workload>/) into the committed summary
+profiles/<name>/{kernel_stats[_wl].csv, pmc_summary[_wl].json, bench_line[_wl].json}:
+   python scripts/summarize_profile.py <tag> <name> [workload]"""
 import collections, csv, glob, json, os, shutil, sys
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 tag, name = sys.argv[1], sys.argv[2]
-src = os.path.join(ROOT, "gpurun_out", "prof_" + tag)
+wl = sys.argv[3] if len(sys.argv) > 3 else "nsq24"
+sfx = "" if wl == "nsq24" else "_" + wl
+src = os.path.join(ROOT, "gpurun_out", "prof_" + tag + "_" + wl)
 dst = os.path.join(ROOT, "profiles", name)
 os.makedirs(dst, exist_ok=True)
 
 stats = glob.glob(os.path.join(src, "trace", "**", "*kernel_stats.csv"), recursive=True)
 if stats:
-    shutil.copy(stats[0], os.path.join(dst, "kernel_stats.csv"))
+    shutil.copy(stats[0], os.path.join(dst, f"kernel_stats{sfx}.csv"))
 summary = {}
 for p in ("pmc_sq", "pmc_lds", "pmc_fetch", "pmc_write"):
     f = glob.glob(os.path.join(src, p, "**", "*counter_collection.csv"), recursive=True)
@@ -32,7 +35,7 @@ for lg in ("trace_bench.log", "pmc_sq.log"):
             if ln.startswith("{") and '"metric"' in ln:
                 line = json.loads(ln)
                 if lg == "trace_bench.log":
-                    json.dump(line, open(os.path.join(dst, "bench_line.json"), "w"), indent=1)
+                    json.dump(line, open(os.path.join(dst, f"bench_line{sfx}.json"), "w"), indent=1)
                 break
     except OSError:
         pass
@@ -41,6 +44,7 @@ for lg in ("trace_bench.log", "pmc_sq.log"):
         # the PMC command is `bench.py --steps 1 --warmup 0 --no-time-to-cov`: exactly one 1e6-scenario launch
         ttc = line.get("time_to_cov_1pct", {}).get("samples", 0)
         scen = n_pmc + ttc
+        summary["units_per_profiled_launch"] = scen
         ev = [k for k in summary if "eval_kernel" in k]
         if ev and "pmc_fetch" in summary[ev[0]] and "pmc_write" in summary[ev[0]]:
             fk = summary[ev[0]]["pmc_fetch"]["sums"]["FETCH_SIZE"]; wk = summary[ev[0]]["pmc_write"]["sums"]["WRITE_SIZE"]
@@ -49,5 +53,5 @@ for lg in ("trace_bench.log", "pmc_sq.log"):
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-time-to-cov` (one 1e6-scenario launch); units KiB; FETCH_SIZE "
                         "doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads), WRITE_SIZE uncalibrated",
                 "fetch_kib": fk, "write_kib": wk, "scenarios": scen, "bytes_per_scenario": b / scen, "bytes_per_1e6_scenario_launch": b / scen * 1e6}
-json.dump(summary, open(os.path.join(dst, "pmc_summary.json"), "w"), indent=1)
+json.dump(summary, open(os.path.join(dst, f"pmc_summary{sfx}.json"), "w"), indent=1)
 print("wrote", dst, sorted(os.listdir(dst)))

@@ -33,6 +33,17 @@ int main(int argc, char** argv)
     if (acc.n != acc2.n || acc.n_fail != acc2.n_fail) return 7;
     uint8_t st[4 * 256]; double dns[4];
     if (relmc_mc_sampling(ctx, 1, 0, 4, st) != RELMC_OK || relmc_mc_simulation(ctx, st, 4, &o, dns, NULL, NULL, NULL) != RELMC_OK) return 8;
+    /* the reference's persistent unique-state database (nsqMain.m:220-278) in two batches: same accumulators */
+    relmc_db_stats ds; relmc_acc acc3;
+    if (relmc_db_reset(ctx) != RELMC_OK || relmc_nsq_db_batch(ctx, 1, 0, 60000, &o, NULL, &ds) != RELMC_OK ||
+        relmc_nsq_db_batch(ctx, 1, 60000, 40000, &o, &acc3, &ds) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 9; }
+    if (acc3.n != acc.n || acc3.n_fail != acc.n_fail || ds.samples != 100000 || ds.rows <= 0 || ds.rows > nd) return 10;
+    /* the path's one collective through the library's own RCCL communicator (a single rank here: the identity) */
+    uint8_t uid[RELMC_COMM_ID_BYTES]; relmc_acc red = acc;
+    if (relmc_comm_unique_id(uid) != RELMC_OK || relmc_comm_init(ctx, 1, 0, uid) != RELMC_OK) { fprintf(stderr, "comm: %s\n", relmc_last_error(ctx)); return 11; }
+    if (relmc_comm_allreduce_acc(ctx, &red) != RELMC_OK) { fprintf(stderr, "comm: %s\n", relmc_last_error(ctx)); return 12; }
+    if (memcmp(&red, &acc, sizeof(acc)) != 0) return 13;
+    relmc_comm_destroy(ctx);
     printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
     relmc_ctx_destroy(ctx);
     return 0;

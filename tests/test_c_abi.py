@@ -42,7 +42,7 @@ def test_plain_c_client(tmp_path, case):
             fh.write(np.ascontiguousarray(a, dtype=t).tobytes())
     out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=300)
     assert out.returncode == 0, out.stderr
-    n, n_fail, sum_dns, nd = out.stdout.split()[:4]
+    n, n_fail, sum_dns, nd = out.stdout.strip().splitlines()[-1].split()[:4]      # RCCL prints a banner before it
     from powersystemsreliabilityassessment_amd import api
     eng = api.Engine(case)
     acc = eng.nsq_accumulate(1, 0, 100000)

@@ -136,3 +136,66 @@ def test_distributed_driver_gloo_world2(tmp_path, oracle):
     assert np.array_equal(got["ti"], si)
     np.testing.assert_allclose(got["td"], sd, rtol=1e-11, atol=1e-9)
     assert float(got["beta"]) <= 0.02 or n >= 60000
+
+
+_AR_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch.distributed as dist
+from powersystemsreliabilityassessment_amd import _abi, dist as rdist
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+dist.init_process_group("gloo", rank=rank, world_size=world)
+ints = np.zeros(_abi.Acc.N_INT, dtype=np.int64); dbls = np.zeros(_abi.Acc.N_DBL)
+ints[0] = (1 << 61) + 12345 + rank            # far above 2^53: must still come out exact
+ints[1] = 7 * (rank + 1); ints[6 + 70] = (1 << 40) + rank
+dbls[0] = 0.1 * (rank + 1); dbls[2 + 23] = 1e-3 + rank
+out = rdist.allreduce_acc(_abi.Acc.from_arrays(ints, dbls))
+if rank == 0:
+    oi, od = out.to_arrays()
+    np.savez(sys.argv[4], oi=oi, od=od)
+dist.destroy_process_group()
+"""
+
+
+def test_allreduce_acc_exact_large_counters(tmp_path):
+    """The accumulator all-reduce carries int64 counters exactly (two fp64 words each), whatever their size, and every
+    rank enters the one collective unconditionally (no rank-local check in front of it)."""
+    script = tmp_path / "ar.py"
+    script.write_text(_AR_WORKER.format(root=ROOT))
+    out = tmp_path / "ar.npz"
+    port = str(29900 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(out)]) for r in range(2)]
+    for p in procs:
+        assert p.wait(timeout=300) == 0
+    got = np.load(out)
+    assert int(got["oi"][0]) == 2 * ((1 << 61) + 12345) + 1 and int(got["oi"][1]) == 21 and int(got["oi"][6 + 70]) == 2 * (1 << 40) + 1
+    assert got["od"][0] == pytest.approx(0.3, rel=1e-15) and got["od"][2 + 23] == pytest.approx(1.002, rel=1e-15)
+
+
+@pytest.mark.gpu
+def test_bench_two_ranks_share_device(tmp_path):
+    """bench.py's N > 1 path (torch.distributed launcher, one all-reduce per step) with two ranks on the one GPU of the box
+    (gloo, --share-device): the merged accumulators of the timed steps equal the single-rank run over the same global
+    scenario range, in weak and in strong scaling."""
+    import json
+    def run(nproc, extra, tag):
+        f = tmp_path / f"acc_{tag}.json"
+        port = str(29700 + (os.getpid() + nproc + len(tag)) % 200)
+        cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
+               "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
+               "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--no-time-to-cov", "--dump-acc", str(f)] + extra
+        out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
+        assert out.returncode == 0, out.stderr[-2000:]
+        line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
+        return json.loads(line), json.load(open(f))
+    j2, a2 = run(2, ["--batch", "50000"], "w2")
+    j1, a1 = run(1, ["--batch", "100000"], "w1")
+    assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["indices"]["n"] == j1["indices"]["n"] == 200000
+    assert a2["ints"] == a1["ints"]
+    np.testing.assert_allclose([float.fromhex(x) for x in a2["dbls"]], [float.fromhex(x) for x in a1["dbls"]], rtol=1e-11, atol=1e-9)
+    for key in ("frac", "frac_executed", "frac_dense_equiv", "lds_pipe_busy", "lds_conflict_frac", "valu_busy", "waves_per_simd", "traffic", "counters_source"):
+        assert key in j1["roofline"], key
+    s2, b2 = run(2, ["--scaling", "strong", "--total", "120000"], "s2")
+    s1, b1 = run(1, ["--scaling", "strong", "--total", "120000"], "s1")
+    assert s2["scaling"] == "strong" and s2["indices"]["n"] == s1["indices"]["n"] == 240000 and b2["ints"] == b1["ints"]
