@@ -188,7 +188,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     double* const LR = W;
     double* const IR = W + 4 * (nlp + 1);
     const int maxdeg = C.maxdeg, maxinj = C.maxinj;
-    double* const Stash = W + a.stash_off + rlane;          // [2*IS][RW]: 1/D and Np/D of this lane's injections
+    double* const Stash = W + a.stash_off + 2 * rlane;      // [IS][RW] pairs {1/D, Np/D} of this lane's injections (one b128 access each)
     double* const Lam = W + a.stash_off + 2 * IS * RW;       // [NBT]: bus multipliers lambda_i (kept across the solve)
     uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
 
@@ -727,7 +727,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         }
                     }
                     if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
-                    Stash[RW * (2 * s)] = invD; Stash[RW * (2 * s + 1)] = npd;
+                    st2(Stash + 2 * RW * s, invD, npd);
                     SLOT_FENCE();
                 }
                 PT_MARK(1)
@@ -960,7 +960,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (I_ON(s)) {
                         dlb[s] = X[2 * (iinfo[s] & 0xff) + 1];
                         if (I_BOX(s)) {
-                            dpv[s] = __builtin_fma(dlb[s], Stash[RW * (2 * s)], -Stash[RW * (2 * s + 1)]);   // dp = (-Np + dlam)/D
+                            const d2 sh = ld2(Stash + 2 * RW * s);
+                            dpv[s] = __builtin_fma(dlb[s], sh.x, -sh.y);   // dp = (-Np + dlam)/D
                             const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
