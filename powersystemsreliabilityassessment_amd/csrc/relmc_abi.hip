@@ -10,6 +10,7 @@
 #include <cstring>
 #include <new>
 #include <string>
+#include <thread>
 #include <vector>
 #include <algorithm>
 #include <cstddef>
@@ -51,6 +52,17 @@ struct relmc_ctx {
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
     double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
     bool db_has_opts = false; relmc_solver_opts db_opts;
+    // host-buffer entry points (relmc_mc_simulation, relmc_seq_mcsimulation): double-buffered chunk pipeline, device buffers
+    // and pinned staging kept across calls
+    struct HostPipe {
+        bool ready = false; int ncomp = 0, nb = 0;
+        hipStream_t up = nullptr, down = nullptr;
+        hipEvent_t e_up[2] = {nullptr, nullptr}, e_ks[2] = {nullptr, nullptr}, e_ke[2] = {nullptr, nullptr}, e_down[2] = {nullptr, nullptr};
+        uint8_t* d_st[2] = {nullptr, nullptr}; double* d_sc[2] = {nullptr, nullptr}; double* d_dns[2] = {nullptr, nullptr}; double* d_nod[2] = {nullptr, nullptr};
+        int32_t* d_stat[2] = {nullptr, nullptr}; int32_t* d_it[2] = {nullptr, nullptr};
+        uint8_t* h_st[2] = {nullptr, nullptr}; double* h_sc[2] = {nullptr, nullptr}; double* h_dns[2] = {nullptr, nullptr}; double* h_nod[2] = {nullptr, nullptr};
+        int32_t* h_stat[2] = {nullptr, nullptr}; int32_t* h_it[2] = {nullptr, nullptr};
+    } pipe;
     // RCCL communicator over the ranks of a multi-GPU run (optional; relmc_comm_*)
     void* comm = nullptr; int comm_nranks = 0, comm_rank = -1;
     // sequential track
@@ -67,6 +79,7 @@ namespace {
 const char* kNoCtx = "relmc: null context";
 void db_free(relmc_ctx* ctx);
 void comm_free(relmc_ctx* ctx);
+void pipe_free(relmc_ctx* ctx);
 
 int fail(relmc_ctx* ctx, int code, const std::string& msg)
 {
@@ -114,7 +127,7 @@ int ensure_partial(relmc_ctx* ctx, size_t bytes)
 
 // launches the evaluation kernel of the active tile; *rows_out = scenario rows holding partial accumulators
 template <int MODE, class TL>
-int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
+int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     const int blocks = grid_for<TL>(ctx, a.n);
     int rc = ensure_partial(ctx, sizeof(PartialT<TL>) * 64 * TL::WPB * (size_t)blocks);
@@ -130,21 +143,21 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
 #else
     a.timing = nullptr;
 #endif
-    HIP_TRY(ctx, hipEventRecord(ctx->ev0, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev_start ? ev_start : ctx->ev0, ctx->stream));
     hipLaunchKernelGGL((relmc_eval_kernel<MODE, TL>), dim3(blocks), dim3(64 * TL::WPB), ctx->lds_bytes, ctx->stream,
                        reinterpret_cast<const DevCaseT<TL>*>(ctx->dcase), a);
     HIP_TRY(ctx, hipGetLastError());
-    HIP_TRY(ctx, hipEventRecord(ctx->ev1, ctx->stream));
+    HIP_TRY(ctx, hipEventRecord(ev_stop ? ev_stop : ctx->ev1, ctx->stream));
     *rows_out = blocks * TL::WPB * TL::SPW;
     return RELMC_OK;
 }
 
 template <int MODE>
-int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out)
+int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
-    if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out);
+    if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out, ev_start, ev_stop);
     if constexpr (MODE == 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "the sequential track is built for the 16-lane tile (<= 128 components)");
-    else return launch_eval_t<MODE, Tile96>(ctx, a, rows_out);
+    else return launch_eval_t<MODE, Tile96>(ctx, a, rows_out, ev_start, ev_stop);
 }
 
 // deterministic reduction of the partial records into the device image of relmc_acc
@@ -527,6 +540,112 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
 }
 
 
+// ---- host-buffer evaluation: states in pageable host memory -> dns / nodal / status / iterations in host memory ---------
+// What a MATLAB / Julia / Python caller of mc_simulation hands over.  The range is cut into chunks of kPipeChunk states that
+// run through a double-buffered pipeline on three streams (H2D, kernel, D2H) with pinned staging buffers; the host copies
+// chunk k in and chunk k-2 out while the GPU works on chunk k-1.  Device and staging buffers are allocated once per context.
+constexpr int64_t kPipeChunk = 131072;
+
+void pipe_free(relmc_ctx* ctx)
+{
+    auto& P = ctx->pipe;
+    for (int b = 0; b < 2; ++b) {
+        for (void* p : {(void*)P.d_st[b], (void*)P.d_sc[b], (void*)P.d_dns[b], (void*)P.d_nod[b], (void*)P.d_stat[b], (void*)P.d_it[b]}) if (p) (void)hipFree(p);
+        for (void* p : {(void*)P.h_st[b], (void*)P.h_sc[b], (void*)P.h_dns[b], (void*)P.h_nod[b], (void*)P.h_stat[b], (void*)P.h_it[b]}) if (p) (void)hipHostFree(p);
+        for (hipEvent_t e : {P.e_up[b], P.e_ks[b], P.e_ke[b], P.e_down[b]}) if (e) (void)hipEventDestroy(e);
+    }
+    if (P.up) (void)hipStreamDestroy(P.up);
+    if (P.down) (void)hipStreamDestroy(P.down);
+    P = relmc_ctx::HostPipe();
+}
+
+int pipe_ensure(relmc_ctx* ctx)
+{
+    auto& P = ctx->pipe;
+    if (P.ready && P.ncomp == ctx->ncomp && P.nb == ctx->nb) return RELMC_OK;
+    pipe_free(ctx);
+    const size_t c = (size_t)kPipeChunk, nc = (size_t)ctx->ncomp, nb = (size_t)ctx->nb;
+    bool ok = hipStreamCreateWithFlags(&P.up, hipStreamNonBlocking) == hipSuccess && hipStreamCreateWithFlags(&P.down, hipStreamNonBlocking) == hipSuccess;
+    for (int b = 0; b < 2 && ok; ++b) {
+        ok = hipEventCreate(&P.e_up[b]) == hipSuccess && hipEventCreate(&P.e_ks[b]) == hipSuccess && hipEventCreate(&P.e_ke[b]) == hipSuccess &&
+             hipEventCreate(&P.e_down[b]) == hipSuccess &&
+             hipMalloc(&P.d_st[b], c * nc) == hipSuccess && hipMalloc(&P.d_sc[b], c * 8) == hipSuccess && hipMalloc(&P.d_dns[b], c * 8) == hipSuccess &&
+             hipMalloc(&P.d_nod[b], c * nb * 8) == hipSuccess && hipMalloc(&P.d_stat[b], c * 4) == hipSuccess && hipMalloc(&P.d_it[b], c * 4) == hipSuccess &&
+             hipHostMalloc(&P.h_st[b], c * nc, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&P.h_sc[b], c * 8, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(&P.h_dns[b], c * 8, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&P.h_nod[b], c * nb * 8, hipHostMallocDefault) == hipSuccess &&
+             hipHostMalloc(&P.h_stat[b], c * 4, hipHostMallocDefault) == hipSuccess && hipHostMalloc(&P.h_it[b], c * 4, hipHostMallocDefault) == hipSuccess;
+    }
+    if (!ok) { pipe_free(ctx); return fail(ctx, RELMC_ERR_HIP, "host-buffer pipeline: allocation failed"); }
+    P.ready = true; P.ncomp = ctx->ncomp; P.nb = ctx->nb;
+    return RELMC_OK;
+}
+
+// memcpy spread over a few threads: one core moves ~8 GB/s, the nodal output of 1e6 states is 200 MB
+void par_memcpy(void* dst, const void* src, size_t bytes)
+{
+    const size_t kMin = (size_t)4 << 20;
+    int nt = bytes / kMin > 4 ? 4 : (int)(bytes / kMin);
+    if (nt <= 1) { std::memcpy(dst, src, bytes); return; }
+    std::vector<std::thread> th;
+    const size_t per = ((bytes / nt) + 63) & ~(size_t)63;
+    for (int t = 1; t < nt; ++t) {
+        const size_t off = per * t, len = t == nt - 1 ? bytes - off : per;
+        th.emplace_back([=]() { std::memcpy((char*)dst + off, (const char*)src + off, len); });
+    }
+    std::memcpy(dst, src, per);
+    for (auto& t : th) t.join();
+}
+
+int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, int64_t n, const relmc_solver_opts& o, double fail_threshold,
+             double* dns, double* nodal, int32_t* status, int32_t* iters)
+{
+    int rc = pipe_ensure(ctx);
+    if (rc) return rc;
+    auto& P = ctx->pipe;
+    const size_t nc = (size_t)ctx->ncomp, nb = (size_t)ctx->nb;
+    const int64_t nchunk = (n + kPipeChunk - 1) / kPipeChunk;
+    double kernel_ms = 0.0;
+    auto drain = [&](int64_t k) -> int {                      // chunk k's results: wait for its D2H, copy out of the staging buffers
+        const int b = (int)(k & 1);
+        const int64_t lo = k * kPipeChunk, m = (n - lo) < kPipeChunk ? (n - lo) : kPipeChunk;
+        HIP_TRY(ctx, hipEventSynchronize(P.e_down[b]));
+        float ms = 0.f;
+        if (hipEventElapsedTime(&ms, P.e_ks[b], P.e_ke[b]) == hipSuccess) kernel_ms += ms;
+        std::memcpy(dns + lo, P.h_dns[b], sizeof(double) * (size_t)m);
+        if (nodal) par_memcpy(nodal + (size_t)lo * nb, P.h_nod[b], sizeof(double) * (size_t)m * nb);
+        if (status) std::memcpy(status + lo, P.h_stat[b], sizeof(int32_t) * (size_t)m);
+        if (iters) std::memcpy(iters + lo, P.h_it[b], sizeof(int32_t) * (size_t)m);
+        return RELMC_OK;
+    };
+    for (int64_t k = 0; k < nchunk; ++k) {
+        const int b = (int)(k & 1);
+        const int64_t lo = k * kPipeChunk, m = (n - lo) < kPipeChunk ? (n - lo) : kPipeChunk;
+        if (k >= 2) { rc = drain(k - 2); if (rc) return rc; }     // frees slot b (device buffers and staging)
+        par_memcpy(P.h_st[b], states + (size_t)lo * nc, (size_t)m * nc);
+        if (load_scale) std::memcpy(P.h_sc[b], load_scale + lo, sizeof(double) * (size_t)m);
+        HIP_TRY(ctx, hipMemcpyAsync(P.d_st[b], P.h_st[b], (size_t)m * nc, hipMemcpyHostToDevice, P.up));
+        if (load_scale) HIP_TRY(ctx, hipMemcpyAsync(P.d_sc[b], P.h_sc[b], sizeof(double) * (size_t)m, hipMemcpyHostToDevice, P.up));
+        HIP_TRY(ctx, hipEventRecord(P.e_up[b], P.up));
+        HIP_TRY(ctx, hipStreamWaitEvent(ctx->stream, P.e_up[b], 0));
+        EvalArgs a = make_args(o);
+        a.fail_threshold = fail_threshold;
+        a.n = m; a.states = P.d_st[b]; a.load_scale = load_scale ? P.d_sc[b] : nullptr;
+        a.dns = P.d_dns[b]; a.nodal = nodal ? P.d_nod[b] : nullptr; a.status = status ? P.d_stat[b] : nullptr; a.iters = iters ? P.d_it[b] : nullptr;
+        int rows = 0;
+        rc = launch_eval<1>(ctx, a, &rows, P.e_ks[b], P.e_ke[b]);
+        if (rc) return rc;
+        HIP_TRY(ctx, hipStreamWaitEvent(P.down, P.e_ke[b], 0));
+        HIP_TRY(ctx, hipMemcpyAsync(P.h_dns[b], P.d_dns[b], sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, P.down));
+        if (nodal) HIP_TRY(ctx, hipMemcpyAsync(P.h_nod[b], P.d_nod[b], sizeof(double) * (size_t)m * nb, hipMemcpyDeviceToHost, P.down));
+        if (status) HIP_TRY(ctx, hipMemcpyAsync(P.h_stat[b], P.d_stat[b], sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, P.down));
+        if (iters) HIP_TRY(ctx, hipMemcpyAsync(P.h_it[b], P.d_it[b], sizeof(int32_t) * (size_t)m, hipMemcpyDeviceToHost, P.down));
+        HIP_TRY(ctx, hipEventRecord(P.e_down[b], P.down));
+    }
+    for (int64_t k = nchunk >= 2 ? nchunk - 2 : 0; k < nchunk; ++k) { rc = drain(k); if (rc) return rc; }
+    ctx->last_kernel_ms = kernel_ms;
+    return RELMC_OK;
+}
+
 }  // namespace
 
 extern "C" {
@@ -575,6 +694,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
     comm_free(ctx);
+    pipe_free(ctx);
     db_free(ctx);
     if (ctx->ev0) (void)hipEventDestroy(ctx->ev0);
     if (ctx->ev1) (void)hipEventDestroy(ctx->ev1);
@@ -697,27 +817,9 @@ int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t 
     if (n < 0 || (n > 0 && (!states_host || !dns_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_mc_simulation: bad arguments");
     if (n == 0) return RELMC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int ncomp = ctx->ncomp, nb = ctx->nb;
-    uint8_t* dst = nullptr; double* ddns = nullptr; double* dnod = nullptr; int32_t* dstat = nullptr; int32_t* dit = nullptr;
-    int rc = RELMC_OK;
-    auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
-    if (hipMalloc(&dst, (size_t)n * ncomp) != hipSuccess || hipMalloc(&ddns, sizeof(double) * n) != hipSuccess ||
-        hipMalloc(&dnod, sizeof(double) * n * nb) != hipSuccess || hipMalloc(&dstat, sizeof(int32_t) * n) != hipSuccess ||
-        hipMalloc(&dit, sizeof(int32_t) * n) != hipSuccess) {
-        cleanup();
-        return fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: device allocation failed");
-    }
-    if (hipMemcpy(dst, states_host, (size_t)n * ncomp, hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: H2D copy failed");
-    if (rc == RELMC_OK) rc = relmc_mc_simulation_dev(ctx, dst, n, opts, ddns, dnod, dstat, dit);
-    if (rc == RELMC_OK) {
-        bool ok = hipMemcpy(dns_host, ddns, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (nodal_host) ok = ok && hipMemcpy(nodal_host, dnod, sizeof(double) * n * nb, hipMemcpyDeviceToHost) == hipSuccess;
-        if (status_host) ok = ok && hipMemcpy(status_host, dstat, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (iters_host) ok = ok && hipMemcpy(iters_host, dit, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) rc = fail(ctx, RELMC_ERR_HIP, "relmc_mc_simulation: D2H copy failed");
-    }
-    cleanup();
-    return rc;
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    return pipe_run(ctx, states_host, nullptr, n, o, 1e-4 /* nsqMain.m:270 */, dns_host, nodal_host, status_host, iters_host);
 }
 
 int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
@@ -1186,33 +1288,7 @@ int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     relmc_solver_opts o;
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
-    const int ncomp = ctx->ncomp, nb = ctx->nb;
-    uint8_t* dst = nullptr; double *dsc = nullptr, *ddns = nullptr, *dnod = nullptr; int32_t *dstat = nullptr, *dit = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dst); (void)hipFree(dsc); (void)hipFree(ddns); (void)hipFree(dnod); (void)hipFree(dstat); (void)hipFree(dit); };
-    if (hipMalloc(&dst, (size_t)n * ncomp) != hipSuccess || hipMalloc(&dsc, sizeof(double) * n) != hipSuccess || hipMalloc(&ddns, sizeof(double) * n) != hipSuccess ||
-        hipMalloc(&dnod, sizeof(double) * n * nb) != hipSuccess || hipMalloc(&dstat, sizeof(int32_t) * n) != hipSuccess || hipMalloc(&dit, sizeof(int32_t) * n) != hipSuccess) {
-        cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: device allocation failed");
-    }
-    int rc = RELMC_OK;
-    if (hipMemcpy(dst, states_host, (size_t)n * ncomp, hipMemcpyHostToDevice) != hipSuccess || hipMemcpy(dsc, load_scale_host, sizeof(double) * n, hipMemcpyHostToDevice) != hipSuccess)
-        rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: H2D copy failed");
-    if (rc == RELMC_OK) {
-        EvalArgs a = make_args(o);
-        a.fail_threshold = 0.01;               // CURTAIL_THRESHOLD, seqMain.m:41
-        a.n = n; a.states = dst; a.load_scale = dsc; a.dns = ddns; a.nodal = dnod; a.status = dstat; a.iters = dit;
-        int blocks = 0;
-        rc = launch_eval<1>(ctx, a, &blocks);
-        if (rc == RELMC_OK) rc = finish_timing(ctx);
-    }
-    if (rc == RELMC_OK) {
-        bool ok = hipMemcpy(dns_host, ddns, sizeof(double) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (nodal_host) ok = ok && hipMemcpy(nodal_host, dnod, sizeof(double) * n * nb, hipMemcpyDeviceToHost) == hipSuccess;
-        if (status_host) ok = ok && hipMemcpy(status_host, dstat, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (iters_host) ok = ok && hipMemcpy(iters_host, dit, sizeof(int32_t) * n, hipMemcpyDeviceToHost) == hipSuccess;
-        if (!ok) rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsimulation: D2H copy failed");
-    }
-    cleanup();
-    return rc;
+    return pipe_run(ctx, states_host, load_scale_host, n, o, 0.01 /* CURTAIL_THRESHOLD, seqMain.m:41 */, dns_host, nodal_host, status_host, iters_host);
 }
 
 int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t n_years, const relmc_solver_opts* opts,
