@@ -23,6 +23,7 @@ Outputs (all small JSON, data only):
   seq_hours_fixture.json  scaled-load hours (state, load factor) with the scipy/HiGHS LP value
                         of seq_mcsimulation.m's scaled model and the numpy MIPS restatement.
 
+  rts96_numfail_fixture.json RTS-96 states on which the device solver ended NUMFAIL in a 1e8-sample run, with all oracles' results
   rts96_states_fixture.json  RTS-96 (case96.py) states with the HiGHS LP value and the numpy
                         MIPS restatement's dns / iterations / status, both policies.
 
@@ -269,6 +270,33 @@ def rts96_fixture(n_sample):
           "; status histogram", np.bincount([x["emulate"]["status"] for x in out["states"]], minlength=4).tolist())
 
 
+def rts96_numfail_fixture(scan_json):
+    """States of a 1e8-sample RTS-96 run (seed 1) on which the DEVICE solver ended "numerically failed"
+    (scripts/numfail96.py on the GPU box; its JSON carries the device's and the C oracle's results): here the numpy MIPS
+    restatement and the HiGHS LP value are added, so the fixture pins what the oracles say about exactly these states."""
+    with open(scan_json) as f:
+        scan = json.load(f)
+    lists = sorted({tuple(x["failed"]) for x in scan["states"]})
+    with mp.Pool(8) as pool:
+        res0 = pool.map(_eval96, [(l, po.REFERENCE_EMULATE) for l in lists], chunksize=2)
+        res1 = pool.map(_eval96, [(l, po.PHYSICAL) for l in lists], chunksize=2)
+    by = {(x["policy"], tuple(x["failed"])): x for x in scan["states"]}
+    out = dict(description="RTS-96 states (seed 1, first 1e8 samples) where the device solver's status was NUMFAIL; per policy: numpy MIPS "
+                           "(status/iters/dns), HiGHS LP value, C oracle and device results as scanned on the GPU box by scripts/numfail96.py",
+               n_scanned=scan["n_scanned"], seed=scan["seed"], states=[])
+    for l, a, b in zip(lists, res0, res1):
+        ent = dict(failed=list(l))
+        for name, r in (("emulate", a), ("physical", b)):
+            sc = by.get((name, l))
+            ent[name] = dict(numpy_mips=dict(status=r["status"], iters=r["iters"], dns=r["dns"]), highs_dns=r["highs_dns"],
+                             c_oracle=sc["c_oracle"] if sc else None, device=sc["gpu"] if sc else None, index=sc["index"] if sc else None)
+        out["states"].append(ent)
+    with open(os.path.join(HERE, "rts96_numfail_fixture.json"), "w") as f:
+        json.dump(out, f)
+    agree = sum(1 for e in out["states"] for n in ("emulate", "physical") if e[n]["c_oracle"] and e[n]["c_oracle"]["status"] == e[n]["numpy_mips"]["status"])
+    print("rts96_numfail_fixture.json:", len(lists), "states; C oracle == numpy MIPS status on", agree, "of", 2 * len(lists))
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -276,7 +304,11 @@ if __name__ == "__main__":
     ap.add_argument("--n-nsq", type=int, default=100000)
     ap.add_argument("--only-seq", action="store_true")
     ap.add_argument("--only-rts96", action="store_true")
+    ap.add_argument("--numfail96", default="", help="scan JSON of scripts/numfail96.py -> rts96_numfail_fixture.json")
     a = ap.parse_args()
+    if a.numfail96:
+        rts96_numfail_fixture(a.numfail96)
+        sys.exit(0)
     if a.only_rts96:
         rts96_fixture(240)
         sys.exit(0)

@@ -327,3 +327,55 @@ def test_state_database_run_to_convergence(engine, oracle):
     rep = b.report()
     assert "Unique states evaluated: %d" % b.database_row_count in rep and "Convergence achieved: YES" in rep
     assert "Top 5 Critical Components" in rep and "Top 5 Buses by EENS" in rep
+
+
+def test_converged_run_vs_golden_within_its_standard_errors(engine, golden):
+    """The reference's golden run (N = 1e5, unseeded, not converged: beta = 1.45 %) against a 2e7-sample run here, every
+    quantity within the GOLDEN run's own standard error (4 sigma), with the per-sample variances taken from the device's
+    state database (exact second and fourth moments over its rows): EDNS, sigma(DNS) (golden 68.3), PLC / LOLE, nodal EENS of
+    every bus, importance of every component, and the beta trajectory.  This is as tight as an unseeded N = 1e5 run can pin
+    anything: the converged EDNS here is +2.1 % (1.4 sigma of the golden run) above the golden value, so "within 1 %" of it
+    cannot be demonstrated by anybody."""
+    n_g = golden["n_samples"]
+    r = engine.nsqMain(beta_limit=0.0, max_iterations=20_000_000, samples_per_batch=2_000_000, seed=1, distinct_states="database")
+    db = engine.db_export()
+    c = db["count"].astype(np.float64); N = c.sum()
+    assert N == 20_000_000 == r.current_iteration
+    mu = (c * db["dns"]).sum() / N
+    m2 = (c * (db["dns"] - mu) ** 2).sum() / N
+    m4 = (c * (db["dns"] - mu) ** 4).sum() / N
+    sigma = np.sqrt(m2)
+    assert mu == pytest.approx(r.accumulated_edns, rel=1e-10)
+    # EDNS and sigma(DNS)
+    g_edns = golden["accumulated_edns"]
+    assert abs(g_edns - mu) < 4 * sigma / np.sqrt(n_g)                       # measured: 1.4 sigma
+    g_sigma = golden["beta_history"][-1] * np.sqrt(n_g) * g_edns             # nsqMain.m:299-301 solved for sigma: 68.3
+    se_sigma = np.sqrt((m4 - m2 ** 2) / n_g) / (2 * sigma)
+    assert abs(g_sigma - sigma) < 4 * se_sigma and 60 < g_sigma < 75
+    # PLC / LOLE
+    plc = r.plc
+    assert abs(golden["accumulated_lole"] / 8760.0 - plc) < 4 * np.sqrt(plc * (1 - plc) / n_g)
+    # nodal EENS per bus: variance of the per-sample nodal shed from the database rows
+    nod_mu = (c[:, None] * db["nodal"]).sum(0) / N
+    nod_var = (c[:, None] * (db["nodal"] - nod_mu) ** 2).sum(0) / N
+    g_nodal = np.array(golden["nodal_eens"])
+    np.testing.assert_allclose(nod_mu, r.nodal_eens, rtol=1e-9, atol=1e-12)
+    assert np.all(np.abs(g_nodal - nod_mu) <= 4 * np.sqrt(nod_var / n_g) + 1e-12)
+    assert np.all(g_nodal[nod_mu == 0] == 0)
+    # component importance: binomial over the golden run's failed samples
+    n_fail_g = golden["accumulated_lole"] / 8760.0 * n_g
+    q = r.comp_importance
+    g_imp = np.array(golden["comp_importance"])
+    assert np.all(np.abs(g_imp - q) <= 4 * np.sqrt(q * (1 - q) / n_fail_g) + 1e-4)
+    # trajectory: beta ~ sigma / (EDNS sqrt(N)) along the golden history (nsqMain.m:304-308), noisy early, tight late
+    gb, ge = np.array(golden["beta_history"]), np.array(golden["edns_history"])
+    nk = 100.0 * np.arange(1, len(gb) + 1)
+    ratio = gb * np.sqrt(nk) * ge / sigma
+    assert np.all(np.abs(ratio[nk >= 20_000] - 1) < 0.12) and np.all(np.abs(ratio[nk >= 2_000] - 1) < 0.45)
+    ours = engine.nsqMain(beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, distinct_states="database")
+    assert len(ours.beta_history) == len(gb) == 1000 and not ours.converged          # the reference's own settings: same 1000 checkpoints
+    ro = ours.beta_history * np.sqrt(nk) * ours.edns_history / sigma
+    assert np.all(np.abs(ro[nk >= 20_000] - 1) < 0.12)
+    assert ours.beta_history[-1] == pytest.approx(gb[-1], rel=0.05)                  # 0.014520 here, 0.014507 golden
+    lines = ours.progress_lines()
+    assert len(lines) == 100 and lines[-1].startswith("Iteration 100000: Beta = 0.0145")
