@@ -136,23 +136,104 @@ function indices(eng::Engine, acc::Acc; hours_per_year=8760.0)
     return out
 end
 
-"nsqMain: `while beta > beta_limit && n < max_iterations` (nsqMain.m:208-318) + post-processing (:345-376)."
-function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption(), distinct_states=false)
+# ---- the reference's persistent unique-state database (nsqMain.m:91-99, 220-278) on the device -------------------------
+
+struct DbStats
+    rows::Int64; samples::Int64; new_rows::Int64; batch_distinct::Int64
+end
+
+db_reset(eng::Engine) = check(ccall((:relmc_db_reset, LIB), Int32, (Ptr{Cvoid},), eng.h), eng.h, "relmc_db_reset")
+
+"One pass of the loop body (dedupe, count bumps of known states, evaluation of the new ones, indices from ALL rows): (Acc of the whole database, DbStats)."
+function nsq_db_batch(eng::Engine, seed::Integer, first_index::Integer, n::Integer, mpopt::SolverOpts=mpoption())
+    acc = Acc(); st = Ref(DbStats(0, 0, 0, 0))
+    check(ccall((:relmc_nsq_db_batch, LIB), Int32, (Ptr{Cvoid}, UInt64, UInt64, Int64, Ref{SolverOpts}, Ref{Acc}, Ref{DbStats}),
+                eng.h, seed, first_index, n, mpopt, acc, st), eng.h, "relmc_nsq_db_batch")
+    return acc, st[]
+end
+
+"state_database rows [first_row, first_row + n_rows) in the reference's column layout (nsqMain.m:91-99)."
+function db_export(eng::Engine, first_row::Integer, n_rows::Integer)
+    ncomp = eng.sys.ng + eng.sys.nl; nb = eng.sys.nb
+    states = Matrix{UInt8}(undef, ncomp, n_rows); count = Vector{Int64}(undef, n_rows); dns = Vector{Float64}(undef, n_rows)
+    flag = Vector{Int32}(undef, n_rows); nodal = Matrix{Float64}(undef, nb, n_rows)
+    check(ccall((:relmc_db_export, LIB), Int32,
+                (Ptr{Cvoid}, Int64, Int64, Ptr{UInt8}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
+                eng.h, first_row, n_rows, states, count, dns, flag, nodal, C_NULL, C_NULL), eng.h, "relmc_db_export")
+    return hcat(Float64.(permutedims(states)), Float64.(count), dns, Float64.(flag), permutedims(nodal))     # the reference's matrix
+end
+
+# ---- multi-GPU: one process per GPU (Distributed / MPI.jl), ONE RCCL all-reduce of the accumulators per convergence check ---
+const COMM_ID_BYTES = 128
+function comm_unique_id()
+    id = Vector{UInt8}(undef, COMM_ID_BYTES)
+    rc = ccall((:relmc_comm_unique_id, LIB), Int32, (Ptr{UInt8},), id)
+    rc == 0 || error("relmc_comm_unique_id failed ($rc)")
+    return id                          # rank 0 broadcasts these 128 bytes by its own means (Distributed.remotecall, MPI.Bcast!, a file)
+end
+comm_init(eng::Engine, nranks::Integer, rank::Integer, id::Vector{UInt8}) =
+    check(ccall((:relmc_comm_init, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{UInt8}), eng.h, nranks, rank, id), eng.h, "relmc_comm_init")
+function comm_allreduce!(eng::Engine, acc::Acc)
+    check(ccall((:relmc_comm_allreduce_acc, LIB), Int32, (Ptr{Cvoid}, Ref{Acc}), eng.h, acc), eng.h, "relmc_comm_allreduce_acc")
+    return acc
+end
+comm_destroy(eng::Engine) = ccall((:relmc_comm_destroy, LIB), Int32, (Ptr{Cvoid},), eng.h)
+
+"nsqMain: `while beta > beta_limit && n < max_iterations` (nsqMain.m:208-318) + post-processing (:345-393).
+distinct_states: false = every sample solved; true = distinct states of each batch solved once; :database = the reference's
+persistent unique-state database across batches.  rank / nranks: scenario-index sharding of every batch over the ranks of a
+communicator set up with comm_init (all-reduce per check).  verbose: the reference's console output."
+function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption(),
+                 distinct_states=false, rank=0, nranks=1, verbose=false)
     total = Acc(); ccall((:relmc_acc_zero, LIB), Cvoid, (Ref{Acc},), total)
-    done = 0; beta = Inf; idx = Indices()
-    beta_history = Float64[]; edns_history = Float64[]
+    done = 0; beta = Inf; idx = Indices(); rows = 0
+    beta_history = Float64[]; edns_history = Float64[]; lole_history = Float64[]; plc_history = Float64[]
+    distinct_states === :database && db_reset(eng)
+    t0 = time()
     while beta > beta_limit && done < max_iterations
         m = min(samples_per_batch, max_iterations - done)
-        part = distinct_states ? nsq_accumulate_distinct(eng, seed, done, m, mpopt)[1] : nsq_accumulate(eng, seed, done, m, mpopt)
-        ccall((:relmc_acc_merge, LIB), Cvoid, (Ref{Acc}, Ref{Acc}), total, part)
+        lo = done + div(m * rank, nranks); cnt = done + div(m * (rank + 1), nranks) - lo       # contiguous slice of the batch
+        if distinct_states === :database
+            part, st = nsq_db_batch(eng, seed, lo, cnt, mpopt); rows = st.rows                 # cumulative accumulators of this rank's database
+            nranks > 1 && comm_allreduce!(eng, part)
+            total = part
+        else
+            part = distinct_states ? nsq_accumulate_distinct(eng, seed, lo, cnt, mpopt)[1] : nsq_accumulate(eng, seed, lo, cnt, mpopt)
+            nranks > 1 && comm_allreduce!(eng, part)
+            ccall((:relmc_acc_merge, LIB), Cvoid, (Ref{Acc}, Ref{Acc}), total, part)
+        end
         done += m
         idx = indices(eng, total); beta = idx.beta
-        push!(beta_history, idx.beta); push!(edns_history, idx.edns)
+        push!(beta_history, idx.beta); push!(edns_history, idx.edns); push!(lole_history, idx.lole); push!(plc_history, idx.plc)
+        if verbose && done % 1000 == 0                                                            # nsqMain.m:314-317
+            println("Iteration ", lpad(done, 6), ": Beta = ", round(idx.beta, digits=6), ", EDNS = ", round(idx.edns, digits=4),
+                    " MW, LOLE = ", round(idx.lole, digits=4), " hr/yr")
+        end
     end
     nb = eng.sys.nb; nc = eng.sys.ng + eng.sys.nl
+    nodal = collect(idx.nodal_eens[1:nb]); imp = collect(idx.comp_importance[1:nc])
+    if verbose                                                                                    # nsqMain.m:325-393
+        println("Total simulation time: ", round(time() - t0, digits=2), " seconds\nTotal iterations: ", done)
+        distinct_states === :database && println("Unique states evaluated: ", rows)
+        println("Convergence achieved: ", beta <= beta_limit ? "YES" : "NO")
+        println("EDNS (Expected Demand Not Supplied): ", round(idx.edns, digits=4), " MW\nLOLE (Loss of Load Expectation): ",
+                round(idx.lole, digits=4), " hours/year\nPLC (Probability of Load Curtailment): ", round(idx.plc, digits=6),
+                "\nBeta (Coefficient of Variation): ", round(idx.beta, digits=6), "\nTop 5 Buses by EENS (MWh/yr):")
+        for k in sortperm(nodal, rev=true)[1:min(5, nb)]
+            nodal[k] > 0 && println("  Bus ", lpad(k, 2), ": ", round(nodal[k] * 8760, digits=4), " MWh/yr")
+        end
+        if total.n_fail > 0
+            println("Top 5 Critical Components (Prob. Down given System Failure):")
+            for c in sortperm(imp, rev=true)[1:min(5, nc)]
+                println("  ", c <= eng.sys.ng ? "Gen " * lpad(c, 2) : "Line " * lpad(c - eng.sys.ng, 2), ": ", round(imp[c] * 100, digits=2), "%")
+            end
+        else
+            println("No failure events recorded to analyze weak points.")
+        end
+    end
     return (accumulated_edns=idx.edns, accumulated_lole=idx.lole, plc=idx.plc, current_beta=idx.beta,
-            current_iteration=done, nodal_eens=collect(idx.nodal_eens[1:nb]),
-            comp_importance=collect(idx.comp_importance[1:nc]), beta_history=beta_history, edns_history=edns_history)
+            current_iteration=done, nodal_eens=nodal, comp_importance=imp, beta_history=beta_history, edns_history=edns_history,
+            lole_history=lole_history, plc_history=plc_history, database_row_count=rows)
 end
 
 # ---- sequential track (Montecarlo_seq/) and HL1 copper sheet (GeneratingAdequacy/PowerSystemAdequacy.jl) ----------------
@@ -234,5 +315,18 @@ function run_non_sequential_mc(eng::Engine, capacity::Vector{Float64}, for_rate:
                 eng.h, seed, 0, n_iterations, acc, C_NULL, C_NULL), eng.h, "relmc_hl1_nsq")
     return (lole_hours_yr=acc.sum_lole / acc.n, eue_mwh_yr=acc.sum_eue / acc.n)
 end
+
+# Layout table of the plain-C structs this file mirrors: tests/test_c_abi.py compiles a C program printing sizeof / offsetof of
+# include/relmc.h's structs and compares with these numbers and with the ctypes mirror, so drift in either mirror is caught
+# without a Julia installation.  (name, sizeof, [(field, offset) ...])
+const LAYOUT = [
+    ("relmc_case_desc", 128, [("base_mva", 0), ("nb", 8), ("ref_bus", 24), ("bus_pd", 32), ("always_up", 112), ("total_load", 120)]),
+    ("relmc_solver_opts", 80, [("singular_policy", 0), ("max_it", 4), ("feastol", 8), ("max_stepsize", 72)]),
+    ("relmc_acc", 8 * (6 + MAX_COMP + 2 + MAX_BUS), [("n", 0), ("comp_fail", 48), ("sum_dns", 48 + 8 * MAX_COMP), ("sum_nodal", 64 + 8 * MAX_COMP)]),
+    ("relmc_indices", 8 * (7 + MAX_BUS + MAX_COMP), [("n", 0), ("edns", 8), ("nodal_eens", 56), ("comp_importance", 56 + 8 * MAX_BUS)]),
+    ("relmc_db_stats", 32, [("rows", 0), ("samples", 8), ("new_rows", 16), ("batch_distinct", 24)]),
+    ("relmc_seq_year", 32, [("ens", 0), ("dlc", 8), ("nlc", 16), ("n_contingency", 24)]),
+    ("relmc_hl1_acc", 40, [("n", 0), ("sum_lole", 8), ("sum_eue2", 32)]),
+]
 
 end # module

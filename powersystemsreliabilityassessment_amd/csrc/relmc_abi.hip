@@ -530,6 +530,9 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, TL>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
+#ifdef RELMC_FORCE_ONE_BLOCK
+    bpc = 1;                              // occupancy experiment: one workgroup per CU
+#endif
     ctx->blocks_per_cu = bpc;
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase, &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

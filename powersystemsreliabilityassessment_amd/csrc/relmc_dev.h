@@ -27,7 +27,10 @@ struct TileT {
     static_assert(BS_ <= 2 && LS_ <= 3 && IS_ <= 4, "the per-lane flag word has room for 2 bus, 3 line and 4 injection slots");
 };
 using Tile24 = TileT<16, 2, 3, 4, 128, 96, 160, 4>;
-using Tile96 = TileT<64, 2, 2, 3, 256, 64, 320, 8>;
+#ifndef RELMC_T96_WPB
+#define RELMC_T96_WPB 8
+#endif
+using Tile96 = TileT<64, 2, 2, 3, 256, 64, 320, RELMC_T96_WPB>;
 constexpr int DEGMAX = 8;          // lines per bus
 constexpr int BINJMAX = 8;         // injections per bus
 
