@@ -468,9 +468,10 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     int maxdeg = 0, maxinj_ = 0;
     for (int i = 0; i < nb; ++i) {
         uint64_t pk = 0;
-        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_nline[i] ? C.b_line[i][e] : 0x7f) << (8 * e);
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_nline[i] ? C.b_line[i][e] : nl) << (8 * e);
         C.b_line8[i] = pk;
         if (C.b_nline[i] > maxdeg) maxdeg = C.b_nline[i];
+        if (C.b_nline[i] > C.maxdeg_s[i / ROWL]) C.maxdeg_s[i / ROWL] = C.b_nline[i];
     }
     int nzero = 0;
     for (int k = nb; k < nb + noff; ++k) if (!has_line[k]) C.zero_off[nzero++] = (uint16_t)(4 * pos[k]);
@@ -493,9 +494,10 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     }
     for (int i = 0; i < nb; ++i) {
         uint64_t pk = 0;
-        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : 0xff) << (8 * e);
+        for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : ninj) << (8 * e);
         C.b_inj8[i] = pk;
         if (C.b_ninj[i] > maxinj_) maxinj_ = C.b_ninj[i];
+        if (C.b_ninj[i] > C.maxinj_s[i / ROWL]) C.maxinj_s[i / ROWL] = C.b_ninj[i];
     }
     C.maxdeg = (uint16_t)maxdeg; C.maxinj = (uint16_t)maxinj_;
     {   // is the intact network connected?  (lets the kernel skip the island search when no line is out)

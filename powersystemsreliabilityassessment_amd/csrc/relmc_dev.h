@@ -59,8 +59,9 @@ struct DevCaseT {
     uint16_t off_rhs, off_p;
     uint16_t npass, npass_upd, npass_inv, nzero;
     uint16_t maxdeg, maxinj, base_connected, pad2;   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
-    uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), 0x7f = none
-    uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, 0xff = none
+    uint16_t maxdeg_s[2], maxinj_s[2];   // longest line / injection list among the buses of bus slot 0 / 1
+    uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), unused entries = nl (the all-zero record)
+    uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, unused entries = ninj (the all-zero record)
     // lines
     double b_bsum[NBT];             // sum of the susceptances of the bus' lines, in list order (all lines in service)
     double l_b[NLT];

@@ -187,7 +187,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     const int nlp = C.nl, nip = C.ninj;
     double* const LR = W;
     double* const IR = W + 4 * (nlp + 1);
-    const int maxdeg = C.maxdeg, maxinj = C.maxinj;
+    const int maxdeg0 = C.maxdeg_s[0], maxdeg1 = C.maxdeg_s[1], maxinj0 = C.maxinj_s[0], maxinj1 = C.maxinj_s[1];   // longest incidence lists per bus slot
     double* const Stash = W + a.stash_off + 2 * rlane;      // [IS][RW] pairs {1/D, Np/D} of this lane's injections (one b128 access each)
     double* const Lam = W + a.stash_off + 2 * IS * RW;       // [NBT]: bus multipliers lambda_i (kept across the solve)
     uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
@@ -686,20 +686,18 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     const int l = RW * s + rlane;
-                    double g = 0.0, lx = 0.0, q = 0.0;
-                    if (L_ON(s)) {
-                        lx = LGv[s];                 // G_l = b_l (lambda_f - lambda_t), carried incrementally
-                        if (L_ACT(s)) {
-                            const double b = lb(s), rr = lr(s);
-                            const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
-                            const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
-                            g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
-                            lx = __builtin_fma(b, lmup[s] - lmum[s], lx);
-                            q = b * ((lmup[s] * hp + gamma) * rzp - (lmum[s] * hm + gamma) * rzm);
-                            mx_gh = vmax(mx_gh, vmax(hp, hm));
-                            mx_z = vmax(mx_z, vmax(lzp[s], lzm[s]));
-                            mx_lammu = vmax(mx_lammu, vmax(lmup[s], lmum[s]));
-                        }
+                    double g = 0.0, q = 0.0;
+                    double lx = LGv[s];              // G_l = b_l (lambda_f - lambda_t), carried incrementally; stays 0 on a line out of service
+                    if (L_ACT(s)) {
+                        const double b = lb(s), rr = lr(s);
+                        const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
+                        const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
+                        g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
+                        lx = __builtin_fma(b, lmup[s] - lmum[s], lx);
+                        q = b * ((lmup[s] * hp + gamma) * rzp - (lmum[s] * hm + gamma) * rzm);
+                        mx_gh = vmax(mx_gh, vmax(hp, hm));
+                        mx_z = vmax(mx_z, vmax(lzp[s], lzm[s]));
+                        mx_lammu = vmax(mx_lammu, vmax(lmup[s], lmum[s]));
                     }
                     gown[s] = g;
                     if (l < nlp) { st2(LR + 4 * l, g, lx); st2(LR + 4 * l + 2, lx + q, LFv[s]); }   // nl / ninj records (they alias W)
@@ -708,23 +706,21 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
-                    double invD = 0.0, npd = 0.0, pv = 0.0;
-                    if (I_ON(s)) {
-                        pv = ip[s];
-                        mx_x = vmax(mx_x, __builtin_fabs(pv));
-                        nanx = nanx || pv != pv;
-                        if (I_BOX(s)) {
-                            const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
-                            const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
-                            const double D = imup[s] * rzp + imum[s] * rzm;
-                            const double lxp = C.i_cost[j] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
-                            const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
-                            invD = frcp(D); npd = np * invD;
-                            mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
-                            mx_gh = vmax(mx_gh, vmax(hp, hm));
-                            mx_z = vmax(mx_z, vmax(izp[s], izm[s]));
-                            mx_lammu = vmax(mx_lammu, vmax(imup[s], imum[s]));
-                        }
+                    double invD = 0.0, npd = 0.0;
+                    const double pv = ip[s];         // stays 0 on an injection out of service
+                    mx_x = vmax(mx_x, __builtin_fabs(pv));
+                    nanx = nanx || pv != pv;
+                    if (I_BOX(s)) {
+                        const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
+                        const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
+                        const double D = imup[s] * rzp + imum[s] * rzm;
+                        const double lxp = C.i_cost[j] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
+                        const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
+                        invD = frcp(D); npd = np * invD;
+                        mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
+                        mx_gh = vmax(mx_gh, vmax(hp, hm));
+                        mx_z = vmax(mx_z, vmax(izp[s], izm[s]));
+                        mx_lammu = vmax(mx_lammu, vmax(imup[s], imum[s]));
                     }
                     if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
                     st2(Stash + 2 * RW * s, invD, npd);
@@ -756,9 +752,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const unsigned long long pl = C.b_line8[bi], pj = C.b_inj8[bi];
 #pragma unroll
                         for (int e = 0; e < DEGMAX; ++e) {
-                            if (e >= maxdeg) break;
+                            if (e >= (t == 0 ? maxdeg0 : maxdeg1)) break;
                             const uint32_t ent = (uint32_t)(pl >> (8 * e)) & 0xffu;
-                            const int l = (ent & 0x7f) == 0x7f ? nlp : (int)(ent & 0x7f);
+                            const int l = (int)(ent & 0x7f);             // unused entries name the all-zero record nl
                             const double sg = (ent & 0x80) ? -1.0 : 1.0;
                             const d2 ra = ld2(LR + 4 * l), rb = ld2(LR + 4 * l + 2);
                             md += ra.x;
@@ -768,9 +764,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         }
 #pragma unroll
                         for (int e = 0; e < BINJMAX; ++e) {
-                            if (e >= maxinj) break;
-                            const uint32_t ent = (uint32_t)(pj >> (8 * e)) & 0xffu;
-                            const int j = ent == 0xff ? nip : (int)ent;
+                            if (e >= (t == 0 ? maxinj0 : maxinj1)) break;
+                            const int j = (int)((uint32_t)(pj >> (8 * e)) & 0xffu);   // unused entries name the all-zero record ninj
                             const d2 ra = ld2(IR + 4 * j);
                             bal -= ra.x; E += ra.y; ssum += IR[4 * j + 2];
                         }
