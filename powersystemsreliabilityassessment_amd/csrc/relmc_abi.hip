@@ -480,10 +480,10 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     for (int j = 0; j < ninj; ++j) {
         if (d->inj_bus[j] < 0 || d->inj_bus[j] >= nb) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: bad injection bus");
         const int bus = ext2int[d->inj_bus[j]];
-        C.i_lo[j] = d->inj_pmin[j] / d->base_mva;
-        C.i_hi[j] = d->inj_pmax[j] / d->base_mva;
-        C.i_cost[j] = d->inj_cost[j] * d->base_mva;
-        C.i_pmin_mw[j] = d->inj_pmin[j];
+        C.i_tab[j][0] = d->inj_pmax[j] / d->base_mva;
+        C.i_tab[j][1] = d->inj_pmin[j] / d->base_mva;
+        C.i_tab[j][2] = d->inj_cost[j] * d->base_mva;
+        C.i_tab[j][3] = d->inj_pmin[j];
         C.i_info[j] = (uint32_t)bus | ((j < ng ? IK_REAL : IK_VIRTUAL) << 8);
         if (C.b_ninj[bus] >= BINJMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: more than 8 injections at a bus");
         C.b_inj[bus][C.b_ninj[bus]++] = (uint8_t)j;

@@ -70,10 +70,9 @@ struct DevCaseT {
     int32_t l_partner[NLT];         // the other line of the same bus pair, -1 if none
     uint16_t l_blk[NLT];            // owner lines: W offset of the pair's off-diagonal block
     // injections (real generators then virtual generators = loads)
-    double i_lo[NIT];               // p.u.
-    double i_hi[NIT];               // p.u.
-    double i_cost[NIT];             // c1 * baseMVA (opf_setup)
-    double i_pmin_mw[NIT];          // original Pmin in MW (nodal shed = Pg - Pmin, mc_simulation.m:86)
+    // per injection {upper bound p.u., lower bound p.u., cost c1 * baseMVA (opf_setup), original Pmin in MW (nodal shed = Pg - Pmin,
+    // mc_simulation.m:86)}: bounds and cost come in with one or two 16-byte LDS reads
+    alignas(16) double i_tab[NIT][4];
     uint32_t i_info[NIT];
     // per-bus incidence
     uint8_t b_nline[NBT];

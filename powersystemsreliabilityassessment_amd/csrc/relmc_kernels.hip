@@ -274,7 +274,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             double cap = 0.0;
             for (int k = 0; k < ng; ++k) {
                 const uint32_t wsel = k < 64 ? (k < 32 ? m0 : m1) : (k < 96 ? m2 : m3);
-                if (!((wsel >> (k & 31)) & 1u)) cap += C.i_hi[k];
+                if (!((wsel >> (k & 31)) & 1u)) cap += C.i_tab[k][0];
             }
             hard = cap * base < C.total_load;
         }
@@ -324,7 +324,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         bool infeas = false, singular = false, iterating = false;
         uint32_t lozero = 0;                 // bit s: lower bound of injection slot s relaxed to 0 (island rules 3, 4)
 #define ISC(s) ((RW * (s) + rlane >= ng) ? lscale : 1.0)      /* virtual generators (loads) scale with the hourly factor */
-#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_lo[RW * (s) + rlane] * ISC(s))
+#define ILO(s) (((lozero >> (s)) & 1u) ? 0.0 : C.i_tab[RW * (s) + rlane][1] * ISC(s))
+#define ILOV(s, lo_) (((lozero >> (s)) & 1u) ? 0.0 : (lo_) * ISC(s))      /* the same from a bound already loaded */
 #pragma unroll
         for (int s = 0; s < LS; ++s) { LFv[s] = 0; LGv[s] = 0; lzp[s] = 1; lzm[s] = 1; lmup[s] = 1; lmum[s] = 1; cBv[s] = 0; }
 #pragma unroll
@@ -461,8 +462,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                                 inI[s] = I_ON(s) && ((R >> (iinfo[s] & 0xff)) & 1u);
                                 if (inI[s]) {
                                     cnt += 1u;
-                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
-                                    losum += C.i_pmin_mw[j] * ISC(s);
+                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_tab[j][0] > 0.0) cnt += 1u << 16;
+                                    losum += C.i_tab[j][3] * ISC(s);
                                 }
                             }
                             cnt = row_add<RW>(cnt); losum = row_sum<RW>(losum);
@@ -481,7 +482,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             }
                             uint32_t nfree = 0;
 #pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[RW * s + rlane] - ILO(s) > 0.0) nfree += 1u;
+                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_tab[RW * s + rlane][0] - ILO(s) > 0.0) nfree += 1u;
                             nfree = row_add<RW>(nfree);
                             if (!nfree) dropped |= 1u << pin;        // rule 5: dependent balance rows
                             pinned |= 1u << pin;
@@ -560,8 +561,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                                 inI[s] = I_ON(s) && ilab[s] == pin;
                                 if (inI[s]) {
                                     cnt += 1u;
-                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_hi[j] > 0.0) cnt += 1u << 16;
-                                    losum += C.i_pmin_mw[j] * ISC(s);
+                                    if (kind == IK_VIRTUAL) cnt += 1u << 8; else if (C.i_tab[j][0] > 0.0) cnt += 1u << 16;
+                                    losum += C.i_tab[j][3] * ISC(s);
                                 }
                             }
                             cnt = row_add<RW>(cnt); losum = row_sum<RW>(losum);
@@ -580,7 +581,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             }
                             uint32_t nfree = 0;
 #pragma unroll
-                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_hi[RW * s + rlane] - ILO(s) > 0.0) nfree += 1u;
+                            for (int s = 0; s < IS; ++s) if (inI[s] && C.i_tab[RW * s + rlane][0] - ILO(s) > 0.0) nfree += 1u;
                             nfree = row_add<RW>(nfree);
 #pragma unroll
                             for (int u = 0; u < BS; ++u)
@@ -650,7 +651,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             for (int s = 0; s < IS; ++s) {
                 const int j = RW * s + rlane;
                 if (I_ON(s)) {
-                    const double hi = C.i_hi[j], lo = ILO(s);
+                    const double hi = C.i_tab[j][0], lo = ILO(s);
                     const bool box = hi - lo > eps;
                     if (box) sf |= 1u << (10 + s);
                     ip[s] = box ? 0.5 * (lo + hi) : hi;
@@ -661,7 +662,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         izp[s] = z; izm[s] = z; imup[s] = mu; imum[s] = mu;
                         nq += 2;
                     }
-                    fl += C.i_cost[j] * ip[s];
+                    fl += C.i_tab[j][2] * ip[s];
                 }
             }
 #pragma unroll
@@ -711,10 +712,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     mx_x = vmax(mx_x, __builtin_fabs(pv));
                     nanx = nanx || pv != pv;
                     if (I_BOX(s)) {
-                        const double hp = pv - C.i_hi[j], hm = ILO(s) - pv;
+                        const d2 hl = ld2(C.i_tab[j]);               // {upper, lower} bound
+                        const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
                         const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                         const double D = imup[s] * rzp + imum[s] * rzm;
-                        const double lxp = C.i_cost[j] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
+                        const double lxp = C.i_tab[j][2] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
                         invD = frcp(D); npd = np * invD;
                         mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
@@ -947,17 +949,18 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     SLOT_FENCE();
                 }
-                double dpv[IS], dlb[IS];
+                double dpv[IS];
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
-                    dpv[s] = 0; dlb[s] = 0;
-                    if (I_ON(s)) {
-                        dlb[s] = X[2 * (iinfo[s] & 0xff) + 1];
+                    dpv[s] = 0;
+                    {
                         if (I_BOX(s)) {
+                            const double dlb = X[2 * (iinfo[s] & 0xff) + 1];
                             const d2 sh = ld2(Stash + 2 * RW * s);
-                            dpv[s] = __builtin_fma(dlb[s], sh.x, -sh.y);   // dp = (-Np + dlam)/D
-                            const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
+                            dpv[s] = __builtin_fma(dlb, sh.x, -sh.y);   // dp = (-Np + dlam)/D
+                            const d2 hl = ld2(C.i_tab[j]);
+                            const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
@@ -984,37 +987,34 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     double zl = 0.0, fl = 0.0;
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
-                        if (L_ON(s)) {
-                            if (L_ACT(s)) {
-                                const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
-                                const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                                const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
-                                const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
-                                lzp[s] = __builtin_fma(alphap, dzp, lzp[s]); lzm[s] = __builtin_fma(alphap, dzm, lzm[s]);
-                                lmup[s] = __builtin_fma(alphad, dmup, lmup[s]); lmum[s] = __builtin_fma(alphad, dmum, lmum[s]);
-                                zl = __builtin_fma(lzp[s], lmup[s], zl); zl = __builtin_fma(lzm[s], lmum[s], zl);
-                            }
-                            LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);
-                            LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
+                        if (L_ACT(s)) {
+                            const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
+                            const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
+                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
+                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
+                            lzp[s] = __builtin_fma(alphap, dzp, lzp[s]); lzm[s] = __builtin_fma(alphap, dzm, lzm[s]);
+                            lmup[s] = __builtin_fma(alphad, dmup, lmup[s]); lmum[s] = __builtin_fma(alphad, dmum, lmum[s]);
+                            zl = __builtin_fma(lzp[s], lmup[s], zl); zl = __builtin_fma(lzm[s], lmum[s], zl);
                         }
+                        LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);      // dF = dG = 0 on a line out of service
+                        LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
                         SLOT_FENCE();
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
-                        if (I_ON(s)) {
-                            if (I_BOX(s)) {
-                                const int j = RW * s + rlane;
-                                const double hp = ip[s] - C.i_hi[j], hm = ILO(s) - ip[s];
-                                const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                                const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
-                                const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
-                                ip[s] = __builtin_fma(alphap, dpv[s], ip[s]);
-                                izp[s] = __builtin_fma(alphap, dzp, izp[s]); izm[s] = __builtin_fma(alphap, dzm, izm[s]);
-                                imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
-                                zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
-                            }
-                            fl = __builtin_fma(C.i_cost[RW * s + rlane], ip[s], fl);
+                        if (I_BOX(s)) {
+                            const int j = RW * s + rlane;
+                            const d2 hl = ld2(C.i_tab[j]);
+                            const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
+                            const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
+                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
+                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
+                            ip[s] = __builtin_fma(alphap, dpv[s], ip[s]);
+                            izp[s] = __builtin_fma(alphap, dzp, izp[s]); izm[s] = __builtin_fma(alphap, dzm, izm[s]);
+                            imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
+                            zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                         }
+                        fl = __builtin_fma(C.i_tab[RW * s + rlane][2], ip[s], fl);      // p = 0 on an injection out of service
                         SLOT_FENCE();
                     }
 #pragma unroll
@@ -1042,7 +1042,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 const int j = RW * s + rlane;
                 shed[s] = 0.0;
                 if (((iinfo[s] >> 8) & 0xff) == IK_VIRTUAL && dns > 0.0) {
-                    const double v = ip[s] * base - C.i_pmin_mw[j] * lscale;     // Pg - Pmin, mc_simulation.m:86
+                    const double v = ip[s] * base - C.i_tab[j][3] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
                 if (MODE != 4 && shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
