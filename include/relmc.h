@@ -44,7 +44,11 @@ typedef enum {
     RELMC_ERR_NO_CASE = -5       /* relmc_case_load has not been called */
 } relmc_status;
 
-/* How states that leave a bus with no in-service branch are evaluated. */
+/* How states that leave a bus with no in-service branch are evaluated.
+ * Known deviation: a MULTI-bus island without the reference bus also makes MATPOWER's KKT matrix singular (a constant angle
+ * shift of the island is a null vector), but what MATLAB's `\` returns on that nearly singular matrix cannot be known
+ * here; such states (about 1e-6 per RTS-24 sample) are solved island-aware under BOTH policies and are not claimed to
+ * emulate the reference.  relmc_acc.n_infeasible / n_singular let a caller bound how many states any policy touched. */
 typedef enum {
     RELMC_REFERENCE_EMULATE = 0, /* MATPOWER/MIPS fails in iteration 1, the start point is
                                     consumed unchecked (mc_simulation.m:41,54): dns = load/2 */
