@@ -179,17 +179,18 @@ def test_bench_two_ranks_share_device(tmp_path):
     (gloo, --share-device): the merged accumulators of the timed steps equal the single-rank run over the same global
     scenario range, in weak and in strong scaling."""
     import json
-    def run(nproc, extra, tag):
+    def run(nproc, extra, tag, ttc=False):
         f = tmp_path / f"acc_{tag}.json"
         port = str(29700 + (os.getpid() + nproc + len(tag)) % 200)
         cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={nproc}", "--master-addr", "127.0.0.1",
                "--master-port", port, os.path.join(ROOT, "bench.py"), "--gpus", str(nproc), "--steps", "2", "--warmup", "1",
-               "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--no-time-to-cov", "--dump-acc", str(f)] + extra
+               "--backend", "gloo", "--share-device", "--no-cpu-baseline", "--dump-acc", str(f)] + ([] if ttc else ["--no-time-to-cov"]) + extra
         out = subprocess.run(cmd, capture_output=True, text=True, timeout=600)
         assert out.returncode == 0, out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
         return json.loads(line), json.load(open(f))
-    j2, a2 = run(2, ["--batch", "50000"], "w2")
+    j2, a2 = run(2, ["--batch", "50000"], "w2", ttc=True)        # with the multi-rank wall time to CoV < 1 %
+    assert j2["time_to_cov_1pct"]["beta"] < 0.01 and j2["time_to_cov_1pct"]["samples"] % 200000 == 0
     j1, a1 = run(1, ["--batch", "100000"], "w1")
     assert j2["n_gpus"] == 2 and j2["scaling"] == "weak" and j2["indices"]["n"] == j1["indices"]["n"] == 200000
     assert a2["ints"] == a1["ints"]
