@@ -156,8 +156,7 @@ template <int MODE>
 int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
 {
     if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out, ev_start, ev_stop);
-    if constexpr (MODE == 2) return fail(ctx, RELMC_ERR_UNSUPPORTED, "the sequential track is built for the 16-lane tile (<= 128 components)");
-    else return launch_eval_t<MODE, Tile96>(ctx, a, rows_out, ev_start, ev_stop);
+    return launch_eval_t<MODE, Tile96>(ctx, a, rows_out, ev_start, ev_stop);
 }
 
 // deterministic reduction of the partial records into the device image of relmc_acc
@@ -1225,12 +1224,12 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_load: no case loaded");
-    if (ctx->tile != 0) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_seq_load: the sequential track is built for the 16-lane tile (<= 128 components)");
     if (!mttf || !mttr || !load_factors || hpy < 1 || hpy > 65535) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: bad arguments");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     SeqCase& q = ctx->hseq;
     std::memset(&q, 0, sizeof(q));
-    q.ncomp = ctx->ncomp; q.hpy = hpy;
+    if (ctx->ncomp > SEQ_NCOMPMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_seq_load: more than 256 components");
+    q.ncomp = ctx->ncomp; q.hpy = hpy; q.mw = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
     for (int k = 0; k < q.ncomp; ++k) {
         if (!(mttf[k] > 0) || !(mttr[k] > 0)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: MTTF / MTTR must be positive");
         q.mttf[k] = mttf[k]; q.mttr[k] = mttr[k];
@@ -1241,7 +1240,8 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
     HIP_TRY(ctx, hipMalloc(&ctx->dlf, sizeof(double) * hpy));
     HIP_TRY(ctx, hipMemcpy(ctx->dseq, &q, sizeof(q), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dlf, load_factors, sizeof(double) * hpy, hipMemcpyHostToDevice));
-    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2, Tile24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    if (ctx->tile == 0) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2, Tile24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    else HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2, Tile96>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     ctx->has_seq = true;
     return RELMC_OK;
 }
@@ -1250,7 +1250,7 @@ namespace {
 // chronology of years [first_year, first_year + n_years) into freshly zeroed device masks
 int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, uint32_t** dmasks_out)
 {
-    const size_t words = (size_t)n_years * ctx->hseq.hpy * 4;
+    const size_t words = (size_t)n_years * ctx->hseq.hpy * ctx->hseq.mw;
     uint32_t* dm = nullptr;
     HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
     if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
@@ -1276,7 +1276,7 @@ int32_t relmc_seq_mcsampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_year,
     const size_t bytes = (size_t)nh * ctx->hseq.ncomp;
     uint8_t* dst = nullptr;
     if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: allocation failed"); }
-    hipLaunchKernelGGL(relmc_seq_expand_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, dm, nh, ctx->hseq.ncomp, dst);
+    hipLaunchKernelGGL(relmc_seq_expand_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, dm, nh, ctx->hseq.ncomp, ctx->hseq.mw, dst);
     if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
         hipMemcpy(state_host, dst, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: kernel / copy failed");
     (void)hipFree(dm); (void)hipFree(dst);
@@ -1318,7 +1318,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         hipMalloc(&dyear, sizeof(double) * 3 * n_years) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: device allocation failed"); }
     std::vector<uint32_t> counts(n_years), off(n_years + 1, 0);
     bool ok = hipMemsetAsync(dcurt, 0, nh * sizeof(double), ctx->stream) == hipSuccess;
-    hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, dhours, dcounts);
+    hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, ctx->hseq.mw, dhours, dcounts);
     ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(counts.data(), dcounts, sizeof(uint32_t) * n_years, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
          hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (!ok) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: compaction failed"); }

@@ -119,7 +119,7 @@ struct EvalArgs {
     unsigned long long* timing;     // profiling builds: [waves][8] phase cycle counters (else null)
     double fail_threshold;          // loss flag: dns > 1e-4 (nsqMain.m:270) / > 0.01 (seqMain.m:41)
     const double* load_scale;       // MODE 1: optional per-scenario load scale factor
-    // MODE 2 (sequential): chronology masks [years][hours][4 x u32], compacted contingency hours, hourly load curve
+    // MODE 2 (sequential): chronology masks [years][hours][OW x u32], compacted contingency hours, hourly load curve
     const uint32_t* seq_masks;
     const uint32_t* seq_offsets;    // [years + 1] exclusive scan of contingency-hour counts
     const uint16_t* seq_hours;      // [years][hours] contingency hours of each year, ascending

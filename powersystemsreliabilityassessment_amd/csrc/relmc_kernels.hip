@@ -343,8 +343,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 while (hi_ - lo_ > 1) { const int mid = (lo_ + hi_) >> 1; if ((int64_t)a.seq_offsets[mid] <= sidx) lo_ = mid; else hi_ = mid; }
                 seq_year = lo_;
                 seq_hour = a.seq_hours[(size_t)seq_year * a.seq_hpy + (size_t)(sidx - a.seq_offsets[seq_year])];
-                const uint32_t* m = a.seq_masks + ((size_t)seq_year * a.seq_hpy + seq_hour) * 4;
-                if (rlane < OW) OB[rlane] = rlane < 4 ? m[rlane] : 0u;
+                const uint32_t* m = a.seq_masks + ((size_t)seq_year * a.seq_hpy + seq_hour) * OW;    // OW mask words per hour
+                if (rlane < OW) OB[rlane] = m[rlane];
                 lscale = a.load_factors[seq_hour];            // seqMain.m:114
             } else if (MODE == 3) {
                 const uint32_t s0 = a.memo_start[sidx];
@@ -1396,20 +1396,21 @@ __global__ void __launch_bounds__(64) relmc_db_final_kernel(const DevAcc* __rest
     }
 }
 
-constexpr int NCOMPMAX = 128;       // component capacity of the sequential chronology and of the HL1 fleet tables
+constexpr int NCOMPMAX = 128;       // unit capacity of the HL1 fleet tables
+constexpr int SEQ_NCOMPMAX = 256;   // component capacity of the sequential chronology (both tiles)
 struct SeqCase {
-    int32_t ncomp, hpy;
-    double mttf[NCOMPMAX], mttr[NCOMPMAX];
+    int32_t ncomp, hpy, mw, pad;    // mw: 32-bit mask words per hour (= the tile's OW: 4 or 8)
+    double mttf[SEQ_NCOMPMAX], mttr[SEQ_NCOMPMAX];
 };
 
 // seq_mcsampling.m:35-76, one thread per (year, component): alternate TTF = round(-MTTF ln U) and
 // TTR = ceil(-MTTR ln U), every year starts all-up (seqMain.m:91 calls it with num_years = 1).  U of event e of
 // component k in global year y = (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key=seed)[e & 3] + 0.5) / 2^32.
-// Down hours are OR-ed into masks[year][hour][4 x u32] (bit k), which must be zero on entry.
+// Down hours are OR-ed into masks[year][hour][mw x u32] (bit k), which must be zero on entry.
 __global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* __restrict__ Q, uint64_t seed, uint64_t first_year,
                                                                  int32_t n_years, uint32_t* __restrict__ masks)
 {
-    const int ncomp = Q->ncomp, hpy = Q->hpy;
+    const int ncomp = Q->ncomp, hpy = Q->hpy, mw = Q->mw;
     const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
     if (t >= (int64_t)n_years * ncomp) return;
     const int y = (int)(t / ncomp), k = (int)(t - (int64_t)y * ncomp);
@@ -1429,7 +1430,7 @@ __global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* 
             long long end = current + dur - 1;
             if (end > hpy - 1) end = hpy - 1;
             for (long long h = current; h <= end; ++h)
-                atomicOr(&masks[((size_t)y * hpy + (size_t)h) * 4 + (k >> 5)], 1u << (k & 31));
+                atomicOr(&masks[((size_t)y * hpy + (size_t)h) * mw + (k >> 5)], 1u << (k & 31));
             current += dur;
         }
         up = !up;
@@ -1437,17 +1438,17 @@ __global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* 
 }
 
 // masks -> uint8 states [years][hours][ncomp] (the materialised seq_mcsampling output)
-__global__ void __launch_bounds__(256) relmc_seq_expand_kernel(const uint32_t* __restrict__ masks, int64_t nhours_total, int ncomp,
+__global__ void __launch_bounds__(256) relmc_seq_expand_kernel(const uint32_t* __restrict__ masks, int64_t nhours_total, int ncomp, int mw,
                                                                uint8_t* __restrict__ states)
 {
     for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nhours_total * ncomp; t += (int64_t)gridDim.x * blockDim.x) {
         const int64_t h = t / ncomp; const int k = (int)(t - h * ncomp);
-        states[t] = (masks[h * 4 + (k >> 5)] >> (k & 31)) & 1u;
+        states[t] = (masks[h * mw + (k >> 5)] >> (k & 31)) & 1u;
     }
 }
 
 // seqMain.m:97-100: hours with at least one component down, kept in ascending order (one workgroup per year)
-__global__ void __launch_bounds__(256) relmc_seq_compact_kernel(const uint32_t* __restrict__ masks, int hpy, uint16_t* __restrict__ hours,
+__global__ void __launch_bounds__(256) relmc_seq_compact_kernel(const uint32_t* __restrict__ masks, int hpy, int mw, uint16_t* __restrict__ hours,
                                                                 uint32_t* __restrict__ counts)
 {
     __shared__ uint32_t wsum[4];
@@ -1458,7 +1459,7 @@ __global__ void __launch_bounds__(256) relmc_seq_compact_kernel(const uint32_t* 
     for (int h0 = 0; h0 < hpy; h0 += 256) {
         const int h = h0 + tid;
         bool f = false;
-        if (h < hpy) { const uint32_t* m = masks + ((size_t)y * hpy + h) * 4; f = (m[0] | m[1] | m[2] | m[3]) != 0; }
+        if (h < hpy) { const uint32_t* m = masks + ((size_t)y * hpy + h) * mw; uint32_t o = 0; for (int q = 0; q < mw; ++q) o |= m[q]; f = o != 0; }
         const uint64_t b = __ballot(f);
         const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
