@@ -47,6 +47,7 @@ struct relmc_ctx {
     int64_t memo_cap = 0; size_t memo_tmp_bytes = 0;
     uint32_t *mk = nullptr, *mperm0 = nullptr, *mperm1 = nullptr, *mhead = nullptr, *muid = nullptr, *mstart = nullptr, *mnu = nullptr;
     unsigned long long *mch0 = nullptr, *mch1 = nullptr; void* mtmp = nullptr;
+    uint32_t *mmiss = nullptr, *mk2 = nullptr;   // probe-first database path: miss list (sample indices) and the masks of the misses
     // persistent state database (nsqMain.m:91-99): rows in HBM, open-addressing table of row ids
     int64_t db_cap = 0, db_n = 0, db_samples = 0; uint64_t db_tcap = 0;
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
@@ -688,7 +689,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     (void)hipSetDevice(ctx->device);
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
     for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
-                    (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
+                    (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp, (void*)ctx->mmiss, (void*)ctx->mk2}) if (p) (void)hipFree(p);
     if (ctx->dcase) (void)hipFree(ctx->dcase);
     if (ctx->dacc) (void)hipFree(ctx->dacc);
     if (ctx->dhl1) (void)hipFree(ctx->dhl1);
@@ -865,10 +866,8 @@ namespace {
 // nsqMain.m:220-229 on the device for the samples [first_index, first_index + m): outage masks (ctx->mk), sample indices
 // sorted by mask (*perm_out; stable, so every run starts with its earliest sample), run starts (ctx->mstart) and the number
 // of distinct states.  Leaves the stream synchronised.
-int memo_prepare(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m, uint32_t* nu_out, uint32_t** perm_out)
+int memo_alloc(relmc_ctx* ctx, int64_t m)
 {
-    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
-    const int nchunk = (ctx->ncomp + 63) / 64;
     size_t tmp_sort = 0, tmp_scan = 0;
     (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
                                     (size_t)m, 0u, 64u, ctx->stream);
@@ -876,25 +875,38 @@ int memo_prepare(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m,
     const size_t tmp_need = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
         for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
-                        (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp}) if (p) (void)hipFree(p);
-        ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
+                        (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp, (void*)ctx->mmiss, (void*)ctx->mk2}) if (p) (void)hipFree(p);
+        ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = ctx->mmiss = ctx->mk2 = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
         ctx->memo_cap = 0; ctx->memo_tmp_bytes = 0;
         HIP_TRY(ctx, hipMalloc(&ctx->mk, sizeof(uint32_t) * (size_t)m * 8));
+        HIP_TRY(ctx, hipMalloc(&ctx->mk2, sizeof(uint32_t) * (size_t)m * 8));
+        HIP_TRY(ctx, hipMalloc(&ctx->mmiss, sizeof(uint32_t) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mperm0, sizeof(uint32_t) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mperm1, sizeof(uint32_t) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mhead, sizeof(uint32_t) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->muid, sizeof(uint32_t) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mstart, sizeof(uint32_t) * ((size_t)m + 1)));
-        HIP_TRY(ctx, hipMalloc(&ctx->mnu, sizeof(uint32_t) * 2));
+        HIP_TRY(ctx, hipMalloc(&ctx->mnu, sizeof(uint32_t) * 4));
         HIP_TRY(ctx, hipMalloc(&ctx->mch0, sizeof(unsigned long long) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mch1, sizeof(unsigned long long) * (size_t)m));
         HIP_TRY(ctx, hipMalloc(&ctx->mtmp, tmp_need));
         ctx->memo_cap = m; ctx->memo_tmp_bytes = tmp_need;
     }
+    return RELMC_OK;
+}
+
+// keys_ready: ctx->mk already holds the m masks (the database's miss list); otherwise they are generated from the sampler
+int memo_prepare(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m, uint32_t* nu_out, uint32_t** perm_out, bool keys_ready = false)
+{
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int nchunk = (ctx->ncomp + 63) / 64;
+    { const int rc = memo_alloc(ctx, m); if (rc) return rc; }
     int64_t gb = (m + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
     const dim3 grid((unsigned)gb), blk(256);
-    if (ctx->tile == 0) hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile24>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index, m, ctx->mk);
-    else hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile96>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index, m, ctx->mk);
+    if (!keys_ready) {
+        if (ctx->tile == 0) hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile24>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase), seed, first_index, m, ctx->mk);
+        else hipLaunchKernelGGL(relmc_memo_keys_kernel<Tile96>, grid, blk, 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase), seed, first_index, m, ctx->mk);
+    }
     hipLaunchKernelGGL(relmc_memo_iota_kernel, grid, blk, 0, ctx->stream, m, ctx->mperm0);
     uint32_t* pin = ctx->mperm0; uint32_t* pout = ctx->mperm1;
     for (int c = 0; c < nchunk; ++c) {               // LSD: stable sort by chunk 0, then 1, ...
@@ -1027,7 +1039,7 @@ int db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out)
     const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
     // the split into blocks depends on the number of rows only, so the fp64 sums do not depend on how the rows arrived
     const uint64_t rows = (uint64_t)ctx->db_n;
-    const uint64_t chunk = 2048;
+    const uint64_t chunk = 256;                          // small chunks: the reduction is latency-bound per block, so use many blocks
     uint64_t nblk = (rows + chunk - 1) / chunk;
     uint64_t per = chunk;
     if (nblk > 4096) { per = (rows + 4095) / 4096; nblk = (rows + per - 1) / per; }
@@ -1084,7 +1096,44 @@ int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, 
         const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t nu = 0; uint32_t* perm = nullptr;
-        int rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &perm);      // :220-229
+        int rc;
+        // A warm database is probed per sample first (most samples are known states: their counts grow right there) and only the
+        // misses go through the dedupe; an empty database takes the whole batch through it.
+        const bool probe_first = ctx->db_n > 0 && !getenv("RELMC_DB_NO_PROBE");
+        if (probe_first) {
+            rc = memo_alloc(ctx, m);
+            if (rc) return rc;
+            uint32_t* dmiss = ctx->mnu + 2;
+            HIP_TRY(ctx, hipMemsetAsync(dmiss, 0, sizeof(uint32_t), ctx->stream));
+            int64_t gp = (m + 1023) / 1024; if (gp > (int64_t)ctx->num_cu * 8) gp = (int64_t)ctx->num_cu * 8;     // 1024 samples per block and flush
+            if (ctx->tile == 0) hipLaunchKernelGGL(relmc_db_probe_kernel<Tile24>, dim3((unsigned)gp), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase),
+                                                   seed, first_index + (uint64_t)done, m, ctx->db_keys, ctx->db_count, ctx->db_table, ctx->db_tcap - 1, ctx->mmiss, ctx->mk2, dmiss);
+            else hipLaunchKernelGGL(relmc_db_probe_kernel<Tile96>, dim3((unsigned)gp), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase),
+                                    seed, first_index + (uint64_t)done, m, ctx->db_keys, ctx->db_count, ctx->db_table, ctx->db_tcap - 1, ctx->mmiss, ctx->mk2, dmiss);
+            HIP_TRY(ctx, hipGetLastError());
+            uint32_t n_miss = 0;
+            HIP_TRY(ctx, hipMemcpyAsync(&n_miss, dmiss, sizeof(n_miss), hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (n_miss == 0) {
+                ctx->db_samples += m;
+                ms_total += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
+                done += m;
+                continue;
+            }
+            // misses in ascending sample order (append order is arbitrary), their masks gathered into the dedupe's key array
+            int64_t gm = ((int64_t)n_miss + 255) / 256; if (gm > (int64_t)ctx->num_cu * 16) gm = (int64_t)ctx->num_cu * 16;
+            hipLaunchKernelGGL(relmc_memo_iota_kernel, dim3((unsigned)gm), dim3(256), 0, ctx->stream, (int64_t)n_miss, ctx->mperm0);
+            uint32_t* idx_sorted = ctx->mhead; uint32_t* pos_sorted = ctx->mperm1;
+            { size_t tb = ctx->memo_tmp_bytes, need = 0;
+              (void)rocprim::radix_sort_pairs(nullptr, need, ctx->mmiss, idx_sorted, ctx->mperm0, pos_sorted, (size_t)n_miss, 0u, 32u, ctx->stream);
+              if (need > tb) return fail(ctx, RELMC_ERR_HIP, "relmc_nsq_db_batch: sort scratch too small");
+              HIP_TRY(ctx, rocprim::radix_sort_pairs(ctx->mtmp, tb, ctx->mmiss, idx_sorted, ctx->mperm0, pos_sorted, (size_t)n_miss, 0u, 32u, ctx->stream)); }
+            hipLaunchKernelGGL(relmc_db_gather_keys_kernel, dim3((unsigned)gm), dim3(256), 0, ctx->stream, ctx->mk2, pos_sorted, ow, n_miss, ctx->mk);
+            HIP_TRY(ctx, hipGetLastError());
+            rc = memo_prepare(ctx, seed, 0, (int64_t)n_miss, &nu, &perm, /*keys_ready=*/true);      // :220-229 on the misses
+        } else {
+            rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &perm);              // :220-229
+        }
         if (rc) return rc;
         rc = db_ensure(ctx, ctx->db_n + (int64_t)nu);
         if (rc) return rc;

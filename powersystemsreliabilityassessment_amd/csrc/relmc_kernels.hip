@@ -1304,6 +1304,88 @@ __global__ void __launch_bounds__(256) relmc_db_insert_kernel(const uint32_t* __
     }
 }
 
+// nsqMain.m:232-245 per SAMPLE, before any sorting (round 2b): every sample of the batch computes its mask and probes the table.
+// Hit (the large majority once the database is warm: >= 96 % on RTS-24): the row's count grows — pre-aggregated per block in a
+// small LDS hash so that the all-up state and the single-outage states do not serialise on one L2 atomic.  Miss: the sample's
+// index and mask are appended to a miss list; only that list goes through the dedupe sort.
+template <class TL>
+__global__ void __launch_bounds__(256) relmc_db_probe_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index, int64_t n,
+                                                             const uint32_t* __restrict__ db_keys, unsigned long long* __restrict__ db_count,
+                                                             const uint32_t* __restrict__ table, uint64_t tmask,
+                                                             uint32_t* __restrict__ miss_idx, uint32_t* __restrict__ miss_keys, uint32_t* __restrict__ n_miss)
+{
+    constexpr int OW = TL::OW;
+    constexpr int LH = 512;
+    __shared__ uint32_t lrow[LH];
+    __shared__ uint32_t lcnt[LH];
+    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2, tid = threadIdx.x;
+    for (int k = tid; k < LH; k += 256) { lrow[k] = DB_EMPTY; lcnt[k] = 0; }
+    __syncthreads();
+    constexpr int SUB = 4;                                   // samples per thread between two flushes of the block's table
+    for (int64_t base = (int64_t)blockIdx.x * 256 * SUB; base < n; base += (int64_t)gridDim.x * 256 * SUB) {
+      for (int sub = 0; sub < SUB; ++sub) {
+        const int64_t i = base + sub * 256 + tid;
+        if (i < n) {
+            const uint64_t gi = first_index + (uint64_t)i;
+            uint32_t w[OW];
+#pragma unroll
+            for (int q = 0; q < OW; ++q) w[q] = 0;
+            for (int blk = 0; blk < nblk; ++blk) {
+                uint32_t r[4];
+                philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+                uint32_t nib = 0;
+#pragma unroll
+                for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
+#pragma unroll
+                for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
+            }
+            uint64_t h = db_hash(w, OW) & tmask;
+            uint32_t found = DB_EMPTY;
+            for (;;) {
+                const uint32_t r = table[h];
+                if (r == DB_EMPTY) break;
+                const uint32_t* dk = db_keys + (size_t)r * OW;
+                bool eq = true;
+#pragma unroll
+                for (int q = 0; q < OW; ++q) eq = eq && dk[q] == w[q];
+                if (eq) { found = r; break; }
+                h = (h + 1) & tmask;
+            }
+            if (found != DB_EMPTY) {
+                uint32_t sl = (found * 2654435761u) >> 23;                 // 9 bits
+                for (int tries = 0; ; ++tries) {
+                    const uint32_t old = atomicCAS(&lrow[sl], DB_EMPTY, found);
+                    if (old == DB_EMPTY || old == found) { atomicAdd(&lcnt[sl], 1u); break; }
+                    if (tries == LH) { atomicAdd(&db_count[found], 1ull); break; }      // block table full: straight to memory
+                    sl = (sl + 1) & (LH - 1);
+                }
+            } else {
+                const uint32_t pos = atomicAdd(n_miss, 1u);
+                miss_idx[pos] = (uint32_t)i;
+#pragma unroll
+                for (int q = 0; q < OW; ++q) miss_keys[(size_t)pos * OW + q] = w[q];
+            }
+        }
+      }
+        __syncthreads();
+        for (int k = tid; k < LH; k += 256) {
+            if (lrow[k] != DB_EMPTY) { atomicAdd(&db_count[lrow[k]], (unsigned long long)lcnt[k]); lrow[k] = DB_EMPTY; lcnt[k] = 0; }
+        }
+        __syncthreads();
+    }
+}
+
+// the misses in ascending sample order: keys[r] = miss_keys[pos_sorted[r]] (the dedupe's stable sort then keeps, within equal masks,
+// the earliest sample first)
+__global__ void __launch_bounds__(256) relmc_db_gather_keys_kernel(const uint32_t* __restrict__ miss_keys, const uint32_t* __restrict__ pos_sorted, int ow,
+                                                                   uint32_t n, uint32_t* __restrict__ keys)
+{
+    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
+        const uint32_t* src = miss_keys + (size_t)pos_sorted[r] * ow;
+        for (int q = 0; q < ow; ++q) keys[(size_t)r * ow + q] = src[q];
+    }
+}
+
 // table of row ids rebuilt after the database has grown
 __global__ void __launch_bounds__(256) relmc_db_rehash_kernel(const uint32_t* __restrict__ db_keys, uint64_t rows, int ow,
                                                               uint32_t* __restrict__ table, uint64_t tmask)
