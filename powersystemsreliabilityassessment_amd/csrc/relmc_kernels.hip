@@ -752,24 +752,32 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         // incidence lists come packed (one 8-byte LDS read each); unused slots point at the zero
                         // records, so all record loads of a bus are independent and issue back to back
                         const unsigned long long pl = C.b_line8[bi], pj = C.b_inj8[bi];
+                        // two list entries per step: their four (three) record loads issue together and one wait covers both;
+                        // an odd list's last step reads the all-zero record once more (adds exact zeros)
 #pragma unroll
-                        for (int e = 0; e < DEGMAX; ++e) {
+                        for (int e = 0; e < DEGMAX; e += 2) {
                             if (e >= (t == 0 ? maxdeg0 : maxdeg1)) break;
-                            const uint32_t ent = (uint32_t)(pl >> (8 * e)) & 0xffu;
-                            const int l = (int)(ent & 0x7f);             // unused entries name the all-zero record nl
-                            const double sg = (ent & 0x80) ? -1.0 : 1.0;
-                            const d2 ra = ld2(LR + 4 * l), rb = ld2(LR + 4 * l + 2);
-                            md += ra.x;
-                            lx = __builtin_fma(sg, ra.y, lx);
-                            nq_ = __builtin_fma(sg, rb.x, nq_);
-                            bal = __builtin_fma(sg, rb.y, bal);
+                            const uint32_t ent0 = (uint32_t)(pl >> (8 * e)) & 0xffu, ent1 = (uint32_t)(pl >> (8 * e + 8)) & 0xffu;
+                            const int l0 = (int)(ent0 & 0x7f), l1 = (int)(ent1 & 0x7f);             // unused entries name the all-zero record nl
+                            const double sg0 = (ent0 & 0x80) ? -1.0 : 1.0, sg1 = (ent1 & 0x80) ? -1.0 : 1.0;
+                            const d2 ra0 = ld2(LR + 4 * l0), rb0 = ld2(LR + 4 * l0 + 2), ra1 = ld2(LR + 4 * l1), rb1 = ld2(LR + 4 * l1 + 2);
+                            md += ra0.x;
+                            lx = __builtin_fma(sg0, ra0.y, lx);
+                            nq_ = __builtin_fma(sg0, rb0.x, nq_);
+                            bal = __builtin_fma(sg0, rb0.y, bal);
+                            md += ra1.x;
+                            lx = __builtin_fma(sg1, ra1.y, lx);
+                            nq_ = __builtin_fma(sg1, rb1.x, nq_);
+                            bal = __builtin_fma(sg1, rb1.y, bal);
                         }
 #pragma unroll
-                        for (int e = 0; e < BINJMAX; ++e) {
+                        for (int e = 0; e < BINJMAX; e += 2) {
                             if (e >= (t == 0 ? maxinj0 : maxinj1)) break;
-                            const int j = (int)((uint32_t)(pj >> (8 * e)) & 0xffu);   // unused entries name the all-zero record ninj
-                            const d2 ra = ld2(IR + 4 * j);
-                            bal -= ra.x; E += ra.y; ssum += IR[4 * j + 2];
+                            const int j0 = (int)((uint32_t)(pj >> (8 * e)) & 0xffu), j1 = (int)((uint32_t)(pj >> (8 * e + 8)) & 0xffu);   // unused entries name the all-zero record ninj
+                            const d2 ra0 = ld2(IR + 4 * j0), ra1 = ld2(IR + 4 * j1);
+                            const double s0 = IR[4 * j0 + 2], s1 = IR[4 * j1 + 2];
+                            bal -= ra0.x; E += ra0.y; ssum += s0;
+                            bal -= ra1.x; E += ra1.y; ssum += s1;
                         }
                         if (B_PIN(t)) {                   // fixed angle: identity row; its multiplier is -lx
                             d00[t] = 1.0; r0[t] = 0.0;
