@@ -298,21 +298,70 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
         std::vector<int> lastw(nunits, -1), lastr(nunits, -1), pkind, pcount;
         std::vector<std::vector<int>> pass_tasks;          // pass -> RW slots, task index or -1
         for (int q = 0; q < MAXPASS; ++q) for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[q][r][k] = 0xffff;   // null task
-        for (size_t ti = 0; ti < tasks.size(); ++ti) {
-            const Task& t = tasks[ti];
-            int ready = 0;
-            for (int r : t.rd) if (lastw[r] + 1 > ready) ready = lastw[r] + 1;          // RAW
-            for (int w : t.wr) { if (lastw[w] + 1 > ready) ready = lastw[w] + 1;        // WAW
-                                 if (lastr[w] > ready) ready = lastr[w]; }               // WAR (same pass is fine: loads precede stores)
-            int p = -1;
-            for (int q = ready; q < (int)pkind.size(); ++q) if (pkind[q] == t.kind && pcount[q] < ROWL) { p = q; break; }
-            if (p < 0) { pkind.push_back(t.kind); pcount.push_back(0); pass_tasks.push_back(std::vector<int>(ROWL, -1)); p = (int)pkind.size() - 1; }
-            if (p >= MAXPASS - 1) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver schedule exceeds MAXPASS");
-            pass_tasks[p][pcount[p]] = (int)ti;
-            pcount[p]++;
-            for (int r : t.rd) if (p > lastr[r]) lastr[r] = p;
-            for (int w : t.wr) lastw[w] = p;
+        // List scheduling by longest remaining dependency path (round 2; the round-1 scheduler placed the tasks as soon as
+        // possible in generation order and needed one more update pass on both test systems).  Dependencies in the sequential
+        // order of `tasks`: read-after-write and write-after-write need a LATER pass, write-after-read allows the SAME pass
+        // (all lanes load before any lane stores).  Phases stay contiguous: all PK_UPD passes, then PK_INV, then PK_BWD.
+        {
+            const int nt = (int)tasks.size();
+            std::vector<std::vector<int>> strict(nt), weak(nt), succ(nt);
+            std::vector<char> succ_w;                                    // parallel to the flattened succ lists: 1 = strict edge
+            std::vector<std::vector<char>> succw(nt);
+            {
+                std::vector<int> lw(nunits, -1);
+                std::vector<std::vector<int>> readers(nunits);
+                for (int i = 0; i < nt; ++i) {
+                    const Task& t = tasks[i];
+                    for (int r : t.rd) if (lw[r] >= 0) strict[i].push_back(lw[r]);
+                    for (int w : t.wr) {
+                        if (lw[w] >= 0) strict[i].push_back(lw[w]);
+                        for (int q : readers[w]) if (q != i) weak[i].push_back(q);
+                    }
+                    for (int r : t.rd) readers[r].push_back(i);
+                    for (int w : t.wr) { lw[w] = i; readers[w].clear(); }
+                }
+                for (int i = 0; i < nt; ++i) {
+                    for (int q : strict[i]) { succ[q].push_back(i); succw[q].push_back(1); }
+                    for (int q : weak[i]) { succ[q].push_back(i); succw[q].push_back(0); }
+                }
+            }
+            std::vector<int> depth(nt, 0), passof(nt, -1);
+            for (int i = nt - 1; i >= 0; --i)
+                for (size_t k = 0; k < succ[i].size(); ++k) {
+                    const int j = succ[i][k];
+                    if (tasks[j].kind == tasks[i].kind && depth[j] + succw[i][k] > depth[i]) depth[i] = depth[j] + succw[i][k];
+                }
+            for (int kind = 0; kind < 3; ++kind) {
+                std::vector<int> remaining;
+                for (int i = 0; i < nt; ++i) if (tasks[i].kind == kind) remaining.push_back(i);
+                while (!remaining.empty()) {
+                    const int cur = (int)pkind.size();
+                    if (cur >= MAXPASS - 1) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver schedule exceeds MAXPASS");
+                    std::vector<int> ready;
+                    for (int i : remaining) {
+                        bool ok = true;
+                        for (int q : strict[i]) if (passof[q] < 0 || passof[q] >= cur) { ok = false; break; }
+                        if (ok) ready.push_back(i);
+                    }
+                    std::stable_sort(ready.begin(), ready.end(), [&](int a2, int b2) { return depth[a2] != depth[b2] ? depth[a2] > depth[b2] : a2 < b2; });
+                    std::vector<int> chosen;
+                    std::vector<char> in_pass(nt, 0);
+                    for (int i : ready) {
+                        if ((int)chosen.size() >= ROWL) break;
+                        bool ok = true;                                   // readers of what this task overwrites: already placed, or in this pass
+                        for (int q : weak[i]) if (passof[q] < 0 && !in_pass[q]) { ok = false; break; }
+                        if (ok) { chosen.push_back(i); in_pass[i] = 1; }
+                    }
+                    if (chosen.empty()) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: solver schedule has a dependency cycle");
+                    pkind.push_back(kind); pcount.push_back((int)chosen.size()); pass_tasks.push_back(std::vector<int>(ROWL, -1));
+                    for (size_t k = 0; k < chosen.size(); ++k) { pass_tasks[cur][k] = chosen[k]; passof[chosen[k]] = cur; }
+                    std::vector<int> rest;
+                    for (int i : remaining) if (passof[i] < 0) rest.push_back(i);
+                    remaining.swap(rest);
+                }
+            }
         }
+        (void)lastw; (void)lastr;
         // ---- LDS bank-conflict aware placement (host only; the passes and their dependencies are untouched).
         // ds_read_b128 serves a wavefront in four fixed 16-lane groups (MI355X_MICROARCH.md), bank = (byte address / 4) mod 64:
         // a group is conflict-free when its 16 lanes hit 16 different 16-byte bank slots.  Two degrees of freedom cost
