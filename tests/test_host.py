@@ -200,3 +200,37 @@ def test_bench_two_ranks_share_device(tmp_path):
     s2, b2 = run(2, ["--scaling", "strong", "--total", "120000"], "s2")
     s1, b1 = run(1, ["--scaling", "strong", "--total", "120000"], "s1")
     assert s2["scaling"] == "strong" and s2["indices"]["n"] == s1["indices"]["n"] == 240000 and b2["ints"] == b1["ints"]
+
+
+def test_nsqmain_report_wording():
+    """The console report of nsqMain.m:314-317, 325-393 from a result object (host formatting only, no device)."""
+    from powersystemsreliabilityassessment_amd import api
+    nodal = np.zeros(24); nodal[[5, 14, 2]] = [2.9, 1.13, 1.0]
+    imp = np.zeros(71); imp[[22, 23, 32, 11, 33 + 5]] = [0.53, 0.54, 0.30, 0.16, 0.03]
+    acc = _abi.Acc(n=3000, n_fail=250)
+    r = api.NsqResult(15.1969, 744.33, 0.084969, 0.0145, 3000, nodal, imp, np.array([0.08, 0.05, 0.0145]), np.array([14.0, 15.5, 15.1969]),
+                      np.array([700.0, 750.0, 744.33]), np.array([0.08, 0.085, 0.084969]), False, 12.19, 1, 0, 0, 2.5, 0.1, acc=acc,
+                      samples_per_batch=1000, beta_limit=0.0017, database_row_count=412, _ng=33)
+    rep = r.report().splitlines()
+    assert rep[0] == "Iteration   1000: Beta = 0.080000, EDNS = 14.0000 MW, LOLE = 700.0000 hr/yr"       # nsqMain.m:315-316
+    assert "Total iterations: 3000" in rep and "Unique states evaluated: 412" in rep and "Convergence achieved: NO" in rep
+    assert "EDNS (Expected Demand Not Supplied): 15.1969 MW" in rep and "PLC (Probability of Load Curtailment): 0.084969" in rep
+    assert rep[rep.index("Top 5 Buses by EENS (MWh/yr):") + 1] == "  Bus  6: 25404.0000 MWh/yr"          # zero buses are not listed (:355)
+    assert sum(1 for ln in rep if ln.startswith("  Bus")) == 3
+    k = rep.index("Top 5 Critical Components (Prob. Down given System Failure):")
+    assert rep[k + 1:k + 6] == ["  Gen 24: 54.00%", "  Gen 23: 53.00%", "  Gen 33: 30.00%", "  Gen 12: 16.00%", "  Line  6: 3.00%"]
+    assert r.top_buses(2) == [(6, pytest.approx(2.9 * 8760)), (15, pytest.approx(1.13 * 8760))]
+    quiet = api.NsqResult(0.0, 0.0, 0.0, float("inf"), 100, np.zeros(24), np.zeros(71), np.array([np.inf]), np.zeros(1), np.zeros(1), np.zeros(1),
+                          False, 12.0, 0, 0, 0, 0.1, 0.0, acc=_abi.Acc(n=100))
+    assert "No failure events recorded to analyze weak points." in quiet.report()
+
+
+def test_bench_counter_fields_come_from_the_committed_profile():
+    """bench.py's pipe utilisations / traffic are read from profiles/<current>/ and say so; every workload has them."""
+    import bench
+    for wl in ("nsq24", "rts96", "seq"):
+        c = bench.counters_from_profile(wl, 1_000_000, 256)
+        assert c["counters_source"].startswith("from_profile: profiles/"), wl
+        assert 0.3 < c["lds_pipe_busy"] < 0.9 and 0.3 < c["valu_busy"] < 0.9 and 0.1 < c["lds_conflict_frac"] < 0.6
+        assert c["waves_per_simd"] == 2.0 and c["mfma_fp64_ops"] == 0.0 and c["traffic"] > 0
+    assert bench.dense_flop_per_iter(24) == pytest.approx(40525.67, rel=1e-6)          # SURVEY 8d: order 47
