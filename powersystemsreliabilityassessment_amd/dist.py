@@ -96,11 +96,14 @@ def indices_from_acc(acc: _abi.Acc, nb: int, ncomp: int, hours_per_year: float =
 
 def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, beta_limit: float = 0.0017,
                         max_samples: int = 100000, batch: int = 100, hours_per_year: float = 8760.0,
-                        rank: int | None = None, world: int | None = None, device=None, allreduce=None):
+                        rank: int | None = None, world: int | None = None, device=None, allreduce=None, cumulative: bool = False):
     """The nsqMain loop (nsqMain.m:208-318) over `world` ranks.
 
     accumulate_fn(seed, first_index, n) -> _abi.Acc evaluates a scenario range on THIS rank
     (Engine.nsq_accumulate in production).  Returns (indices dict, merged Acc, history list).
+    cumulative=True: accumulate_fn returns the accumulators of EVERYTHING this rank has evaluated so far (the rank's own
+    persistent state database: lambda s, lo, n: engine.nsq_db_batch(s, lo, n)[0]); the all-reduced result then IS the
+    running total instead of an increment.
     """
     import torch.distributed as dist
     if rank is None or world is None:
@@ -114,9 +117,9 @@ def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, be
     while beta > beta_limit and done < max_samples:
         m = min(batch, max_samples - done)
         lo, cnt = shard_range(done, m, rank, world)
-        part = accumulate_fn(seed, lo, cnt) if cnt > 0 else _abi.Acc()
+        part = accumulate_fn(seed, lo, cnt) if (cnt > 0 or cumulative) else _abi.Acc()
         part = allreduce(part) if allreduce is not None else allreduce_acc(part, device)
-        total = merge(total, part)
+        total = part if cumulative else merge(total, part)
         done += m
         idx = indices_from_acc(total, nb, ncomp, hours_per_year)
         beta = idx["beta"]
