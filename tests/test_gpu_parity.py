@@ -379,3 +379,22 @@ def test_converged_run_vs_golden_within_its_standard_errors(engine, golden):
     assert ours.beta_history[-1] == pytest.approx(gb[-1], rel=0.05)                  # 0.014520 here, 0.014507 golden
     lines = ours.progress_lines()
     assert len(lines) == 100 and lines[-1].startswith("Iteration 100000: Beta = 0.0145")
+
+
+def test_full_size_properties_1e8_eight_shards(engine):
+    """BASELINE configs[2] size (1e8 samples over 8 shards) on the one GPU of the box: the eight shards' accumulators merged the way
+    the all-reduce merges them == the state database fed with the same 1e8 samples (two entirely different routes: every sample
+    solved vs. 5.5e5 distinct states solved once and counted) — integers identical, sums to 1e-12; beta lands at 0.046 %."""
+    from powersystemsreliabilityassessment_amd import dist
+    n, seed = 100_000_000, 1
+    merged = _abi.Acc()
+    for r in range(8):
+        lo, cnt = dist.shard_range(0, n, r, 8)
+        merged = dist.merge(merged, engine.nsq_accumulate(seed, lo, cnt))
+    db = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=4_000_000, seed=seed, distinct_states="database")
+    mi, md = merged.to_arrays(); di, dd = db.acc.to_arrays()
+    assert np.array_equal(mi, di) and merged.n == n and merged.n_nonconverged == 0
+    np.testing.assert_allclose(md, dd, rtol=1e-12, atol=1e-6)
+    ix = dist.indices_from_acc(merged, engine.case.nb, engine.case.ncomp)
+    assert 0.00044 < ix["beta"] < 0.00048 and abs(ix["edns"] - 15.197) < 0.02 and abs(ix["plc"] - 0.084969) < 1e-4
+    assert 400_000 < db.database_row_count < 700_000
