@@ -1,5 +1,5 @@
 """How many wavefront iterations do different row-grouping policies cost?  (model of relmc_eval_kernel's trip counts)"""
-import sys; sys.path.insert(0,'/root/repo')
+import os, sys; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
 from powersystemsreliabilityassessment_amd import api
 e=api.Engine(); c=e.case; n=1_000_000
