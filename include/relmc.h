@@ -208,8 +208,9 @@ int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
  * count | dns | failure flag | Nb nodal values, nsqMain.m:91-99).  Per batch it removes duplicates (:220-229), bumps the
  * counts of states already in the database (:232-245), evaluates only the new ones (:257-263), appends them (:269-278)
  * and recomputes the indices from all rows (:282-301).  The same on the device: rows in HBM, an open-addressing table of
- * row ids, new rows appended in the order of first appearance in the sample stream (unique(...,'stable')), so the
- * database and every sum over it depend on (seed, samples drawn) only, not on the batch size.
+ * row ids (probed per sample once the database is warm; only the misses are sorted and deduplicated), new rows appended in
+ * the order of first appearance in the sample stream (unique(...,'stable')), so the database and every sum over it depend
+ * on (seed, samples drawn) only, not on the batch size.
  *   relmc_db_reset       empty database (relmc_case_load does the same)
  *   relmc_nsq_db_batch   one pass of the loop body over samples [first_index, first_index + n); acc_out (optional) =
  *                        accumulators of the WHOLE database afterwards (cumulative, not the batch's increment)
@@ -221,7 +222,8 @@ typedef struct {
     int64_t rows;             /* distinct states in the database (database_row_count)     */
     int64_t samples;          /* samples they stand for (sum of the count column)          */
     int64_t new_rows;         /* states evaluated by this call (num_new_states, :255)       */
-    int64_t batch_distinct;   /* distinct states of this call's samples before the lookup   */
+    int64_t batch_distinct;   /* distinct states among this call's samples that went through the dedupe: all of
+                                 them on an empty database, only the misses of the per-sample probe on a warm one */
 } relmc_db_stats;
 int32_t relmc_db_reset(relmc_ctx* ctx);
 int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
