@@ -303,8 +303,8 @@ class Engine:
     def nsqMain(self, beta_limit: float = 0.0017, max_iterations: int = 100000,
                 samples_per_batch: int = 100, *, seed: int = 1, mpopt=None,
                 hours_per_year: float = 8760.0, distinct_states: bool | int | str = False, verbose: bool = False) -> NsqResult:
-        """Defaults are the reference's (nsqMain.m:60-62).  On a GPU a batch of 100 is tiny; pass
-        samples_per_batch >= 1e5 for throughput — the estimators do not depend on the batch size.
+        """Defaults are the reference's (nsqMain.m:60-62).  Small batches are evaluated many checkpoints per launch by the
+        library, so the reference's batch of 100 costs about the same as one large batch.
         distinct_states: False = every sample solved; True / 1 = distinct states of each batch solved once;
         "database" / 2 = the reference's persistent unique-state database across batches (nsqMain.m:220-278).
         verbose: print what the reference prints (progress every 1000 samples, results, top-5 buses / components)."""

@@ -43,6 +43,7 @@ struct relmc_ctx {
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
     unsigned long long* dtiming = nullptr; int timing_waves = 0;
+    double* dhist = nullptr; double* hhist = nullptr /* pinned */; int64_t hist_cap = 0;   // per-sample dns of one launch (checkpoint histories of small batches, relmc_nsq_run)
     // distinct-state path: device buffers sized for memo_cap samples
     int64_t memo_cap = 0; size_t memo_tmp_bytes = 0;
     uint32_t *mk = nullptr, *mperm0 = nullptr, *mperm1 = nullptr, *mhead = nullptr, *muid = nullptr, *mstart = nullptr, *mnu = nullptr;
@@ -53,6 +54,7 @@ struct relmc_ctx {
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
     double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
     bool db_has_opts = false; relmc_solver_opts db_opts;
+    unsigned long long* db_snap = nullptr; int64_t db_snap_cap = 0;      // row counts before a stretch of small batches (relmc_nsq_run)
     // host-buffer entry points (relmc_mc_simulation, relmc_seq_mcsimulation): double-buffered chunk pipeline, device buffers
     // and pinned staging kept across calls
     struct HostPipe {
@@ -572,7 +574,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     ctx->scen_doubles = scen;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
-    ctx->lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? 1024u * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
+    ctx->lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
@@ -747,6 +749,8 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dsorted) (void)hipFree(ctx->dsorted);
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
+    if (ctx->dhist) (void)hipFree(ctx->dhist);
+    if (ctx->hhist) (void)hipHostFree(ctx->hhist);
     comm_free(ctx);
     pipe_free(ctx);
     db_free(ctx);
@@ -876,8 +880,19 @@ int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t 
     return pipe_run(ctx, states_host, nullptr, n, o, 1e-4 /* nsqMain.m:270 */, dns_host, nodal_host, status_host, iters_host);
 }
 
+namespace {
+int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts, relmc_acc* acc_out, double* dns_dev);
+}
+
 int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
                              relmc_acc* acc_out)
+{
+    return nsq_accumulate_impl(ctx, seed, first_index, n, opts, acc_out, nullptr);
+}
+
+namespace {
+// dns_dev (optional, n doubles): dns of every sample of the range in sampling order, beside the accumulators
+int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts, relmc_acc* acc_out, double* dns_dev)
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_accumulate: no case loaded");
@@ -894,6 +909,7 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
         const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
         EvalArgs a = make_args(o);
         a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
+        a.dns = dns_dev ? dns_dev + done : nullptr;
         int blocks = 0;
         int rc = launch_eval<0>(ctx, a, &blocks);
         if (rc) return rc;
@@ -910,6 +926,7 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
     ctx->last_kernel_ms = ms_total;
     return RELMC_OK;
 }
+}  // namespace
 
 namespace {
 // nsqMain.m:220-229 on the device for the samples [first_index, first_index + m): outage masks (ctx->mk), sample indices
@@ -1029,7 +1046,8 @@ namespace {
 void db_free(relmc_ctx* ctx)
 {
     for (void* p : {(void*)ctx->db_keys, (void*)ctx->db_count, (void*)ctx->db_dns, (void*)ctx->db_meta, (void*)ctx->db_nodal, (void*)ctx->db_table,
-                    (void*)ctx->db_partial}) if (p) (void)hipFree(p);
+                    (void*)ctx->db_partial, (void*)ctx->db_snap}) if (p) (void)hipFree(p);
+    ctx->db_snap = nullptr; ctx->db_snap_cap = 0;
     ctx->db_keys = nullptr; ctx->db_count = nullptr; ctx->db_dns = nullptr; ctx->db_meta = nullptr; ctx->db_nodal = nullptr; ctx->db_table = nullptr;
     ctx->db_partial = nullptr; ctx->db_partial_cap = 0;
     ctx->db_cap = 0; ctx->db_n = 0; ctx->db_samples = 0; ctx->db_tcap = 0; ctx->db_has_opts = false;
@@ -1523,6 +1541,113 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     double beta = INFINITY, kernel_ms = 0.0;
     int64_t done = 0, cp = 0;
     if (o->distinct_states == 2) { const int rc0 = relmc_db_reset(ctx); if (rc0) return rc0; }
+    auto checkpoint = [&](const relmc_indices& ix) {
+        if (cp < o->history_cap) {
+            if (o->beta_history) o->beta_history[cp] = ix.beta;
+            if (o->edns_history) o->edns_history[cp] = ix.edns;
+            if (o->lole_history) o->lole_history[cp] = ix.lole;
+            if (o->plc_history) o->plc_history[cp] = ix.plc;
+        }
+        cp++;
+    };
+    // Small batches (the reference's own is 100 samples, nsqMain.m:60) would make every checkpoint one launch of a nearly
+    // empty grid.  They are evaluated many at a time instead: one pass returns the accumulators of the whole stretch and
+    // the dns of each of its samples; the four indices of every checkpoint inside it (nsqMain.m:286-301 need only the dns
+    // sums and the loss count) follow on the host.  If beta reaches its limit inside the stretch, the stretch is cut at that
+    // checkpoint and taken again over the shorter range (the database is first put back to its rows and counts of before
+    // the stretch), so that the result is the one of the batch-by-batch loop.
+    constexpr int64_t kStretch = 1 << 18;
+    if ((o->distinct_states == 0 || o->distinct_states == 2) && o->batch <= kStretch / 2 &&
+        !std::getenv("RELMC_NSQ_NO_STRETCH") /* diagnosis: one launch per batch */) {
+        const bool use_db = o->distinct_states == 2;
+        const int64_t per = kStretch / o->batch * o->batch;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ctx->hist_cap < per) {
+            if (ctx->dhist) (void)hipFree(ctx->dhist);
+            if (ctx->hhist) (void)hipHostFree(ctx->hhist);
+            ctx->dhist = ctx->hhist = nullptr; ctx->hist_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dhist, sizeof(double) * (size_t)per));
+            HIP_TRY(ctx, hipHostMalloc(&ctx->hhist, sizeof(double) * (size_t)per, hipHostMallocDefault));
+            ctx->hist_cap = per;
+        }
+        const double* const hd = ctx->hhist;
+        while (beta > o->beta_limit && done < o->max_samples) {
+            const int64_t m = (o->max_samples - done) < per ? (o->max_samples - done) : per;
+            relmc_acc part;
+            int rc;
+            const int64_t rows0 = ctx->db_n, samples0 = ctx->db_samples;
+            if (use_db) {
+                if (rows0 > ctx->db_snap_cap) {
+                    if (ctx->db_snap) (void)hipFree(ctx->db_snap);
+                    ctx->db_snap = nullptr; ctx->db_snap_cap = 0;
+                    HIP_TRY(ctx, hipMalloc(&ctx->db_snap, sizeof(unsigned long long) * (size_t)ctx->db_cap));
+                    ctx->db_snap_cap = ctx->db_cap;
+                }
+                if (rows0) HIP_TRY(ctx, hipMemcpyAsync(ctx->db_snap, ctx->db_count, sizeof(unsigned long long) * (size_t)rows0, hipMemcpyDeviceToDevice, ctx->stream));
+                rc = relmc_nsq_db_batch(ctx, o->seed, (uint64_t)done, m, &o->solver, nullptr, nullptr);
+                if (rc) return rc;
+                kernel_ms += ctx->last_kernel_ms;
+                int64_t gs = (m + 255) / 256; if (gs > (int64_t)ctx->num_cu * 16) gs = (int64_t)ctx->num_cu * 16;
+                if (ctx->tile == 0) hipLaunchKernelGGL(relmc_db_sample_dns_kernel<Tile24>, dim3((unsigned)gs), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase),
+                                                       o->seed, (uint64_t)done, m, ctx->db_keys, ctx->db_dns, ctx->db_table, ctx->db_tcap - 1, ctx->dhist);
+                else hipLaunchKernelGGL(relmc_db_sample_dns_kernel<Tile96>, dim3((unsigned)gs), dim3(256), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase),
+                                        o->seed, (uint64_t)done, m, ctx->db_keys, ctx->db_dns, ctx->db_table, ctx->db_tcap - 1, ctx->dhist);
+                HIP_TRY(ctx, hipGetLastError());
+            } else {
+                rc = nsq_accumulate_impl(ctx, o->seed, (uint64_t)done, m, &o->solver, &part, ctx->dhist);
+                if (rc) return rc;
+                kernel_ms += ctx->last_kernel_ms;
+            }
+            HIP_TRY(ctx, hipMemcpyAsync(ctx->hhist, ctx->dhist, sizeof(double) * (size_t)m, hipMemcpyDeviceToHost, ctx->stream));
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            relmc_acc run = res->acc;                       // only n, n_fail, sum_dns, sum_dns2 are advanced per checkpoint
+            int64_t used = 0;
+            while (used < m) {
+                const int64_t b = (m - used) < o->batch ? (m - used) : o->batch;
+                double sd = 0.0, sd2 = 0.0; int64_t nf = 0;
+                for (int64_t i = used; i < used + b; ++i) { const double v = hd[(size_t)i]; sd += v; sd2 = std::fma(v, v, sd2); nf += v > 1e-4 /* nsqMain.m:270 */; }
+                if (sd != sd) return fail(ctx, RELMC_ERR_HIP, "relmc_nsq_run: a sampled state is missing from the database");
+                run.n += b; run.n_fail += nf; run.sum_dns += sd; run.sum_dns2 += sd2;
+                used += b;
+                relmc_indices ix;
+                relmc_nsq_indices(&run, 0, 0, o->hours_per_year, &ix);
+                beta = ix.beta;
+                checkpoint(ix);
+                if (beta <= o->beta_limit) break;
+            }
+            if (used < m && use_db) {                          // stopped inside the stretch: the database as it was, then the shorter range
+                ctx->db_n = rows0; ctx->db_samples = samples0;
+                if (rows0) HIP_TRY(ctx, hipMemcpyAsync(ctx->db_count, ctx->db_snap, sizeof(unsigned long long) * (size_t)rows0, hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemsetAsync(ctx->db_table, 0xff, sizeof(uint32_t) * ctx->db_tcap, ctx->stream));
+                if (rows0) {
+                    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+                    int64_t gb = (rows0 + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
+                    hipLaunchKernelGGL(relmc_db_rehash_kernel, dim3((unsigned)gb), dim3(256), 0, ctx->stream, ctx->db_keys, (uint64_t)rows0, ow, ctx->db_table, ctx->db_tcap - 1);
+                    HIP_TRY(ctx, hipGetLastError());
+                }
+                rc = relmc_nsq_db_batch(ctx, o->seed, (uint64_t)done, used, &o->solver, nullptr, nullptr);
+                if (rc) return rc;
+                kernel_ms += ctx->last_kernel_ms;
+            } else if (used < m) {
+                rc = relmc_nsq_accumulate(ctx, o->seed, (uint64_t)done, used, &o->solver, &part);
+                if (rc) return rc;
+                kernel_ms += ctx->last_kernel_ms;
+            }
+            if (use_db) {
+                const auto t1 = std::chrono::steady_clock::now();
+                rc = db_accumulate(ctx, &res->acc);                    // nsqMain.m:282-301 over all rows
+                if (rc) return rc;
+                kernel_ms += std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t1).count();
+            } else relmc_acc_merge(&res->acc, &part);
+            done += used;
+            // the stretch's last checkpoint from the accumulators themselves (what the caller is handed), not from the host sums
+            relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
+            beta = res->idx.beta;
+            cp--;
+            checkpoint(res->idx);
+        }
+    }
+    else
     while (beta > o->beta_limit && done < o->max_samples) {
         const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;
         relmc_acc part;
@@ -1540,13 +1665,7 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         done += m;
         relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
         beta = res->idx.beta;
-        if (cp < o->history_cap) {
-            if (o->beta_history) o->beta_history[cp] = res->idx.beta;
-            if (o->edns_history) o->edns_history[cp] = res->idx.edns;
-            if (o->lole_history) o->lole_history[cp] = res->idx.lole;
-            if (o->plc_history) o->plc_history[cp] = res->idx.plc;
-        }
-        cp++;
+        checkpoint(res->idx);
     }
     res->checkpoints = cp < o->history_cap ? cp : o->history_cap;     // history entries written
     res->batches = cp;

@@ -242,6 +242,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     constexpr bool WINDOWED = (MODE == 0 && RW == 16);
     uint32_t* const WIN = reinterpret_cast<uint32_t*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) +
                           (size_t)SPW * WPB * a.scen_doubles * 2 + (size_t)(tid >> 6) * 256;      // [64 slots][4 words] per wavefront
+    // slot -> sampling lane of the window (the scenario's position in the sampled range), read only when per-scenario dns is asked for
+    uint8_t* const WINL = reinterpret_cast<uint8_t*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) +
+                          ((size_t)SPW * WPB * a.scen_doubles * 2 + (size_t)WPB * 256) * 4 + (size_t)(tid >> 6) * 64;
     int64_t wb_begin = gwave, wb_end = ngroups, wb_step = gstride;
     if (WINDOWED) {
         wb_begin = ngroups * gwave / gstride; wb_end = ngroups * (gwave + 1) / gstride; wb_step = 16;
@@ -285,6 +288,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             const uint32_t slot = hard ? n_easy + (uint32_t)__popcll(bh & below) : (uint32_t)__popcll(bv & ~bh & below);
             uint4 pk; pk.x = m0; pk.y = m1; pk.z = m2; pk.w = m3;
             *reinterpret_cast<uint4*>(WIN + 4 * slot) = pk;
+            WINL[slot] = (uint8_t)lane;
         }
         RELOAD_FENCE();
         win_valid = n_valid;
@@ -1072,6 +1076,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 acc_it += (uint32_t)it * wgt;
             }
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
+            if (MODE == 0 && a.dns && rlane == 0)      // optional: dns of every sample in sampling order (checkpoint histories of small batches)
+                a.dns[WINDOWED ? wb * 4 + WINL[wg * 4 + lane / RW] : sidx] = dns;
             if (MODE == 1 || MODE == 4) {
                 const int64_t oidx = MODE == 4 ? a.db_first + sidx : sidx;       // MODE 4: the database row
 #pragma unroll
@@ -1380,6 +1386,46 @@ __global__ void __launch_bounds__(256) relmc_db_probe_kernel(const DevCaseT<TL>*
             if (lrow[k] != DB_EMPTY) { atomicAdd(&db_count[lrow[k]], (unsigned long long)lcnt[k]); lrow[k] = DB_EMPTY; lcnt[k] = 0; }
         }
         __syncthreads();
+    }
+}
+
+// dns of every sample of a range whose states are all in the database already (the range has just been through
+// relmc_nsq_db_batch): out[i] = dns of the row holding sample i's state, NaN if there is none.  Feeds the per-checkpoint
+// indices of small batches (relmc_nsq_run), which need the order of the samples the count-weighted rows no longer have.
+template <class TL>
+__global__ void __launch_bounds__(256) relmc_db_sample_dns_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index, int64_t n,
+                                                                  const uint32_t* __restrict__ db_keys, const double* __restrict__ db_dns,
+                                                                  const uint32_t* __restrict__ table, uint64_t tmask, double* __restrict__ out)
+{
+    constexpr int OW = TL::OW;
+    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2;
+    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
+        const uint64_t gi = first_index + (uint64_t)i;
+        uint32_t w[OW];
+#pragma unroll
+        for (int q = 0; q < OW; ++q) w[q] = 0;
+        for (int blk = 0; blk < nblk; ++blk) {
+            uint32_t r[4];
+            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
+            uint32_t nib = 0;
+#pragma unroll
+            for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
+#pragma unroll
+            for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
+        }
+        uint64_t h = db_hash(w, OW) & tmask;
+        double v = __builtin_nan("");
+        for (;;) {
+            const uint32_t r = table[h];
+            if (r == DB_EMPTY) break;
+            const uint32_t* dk = db_keys + (size_t)r * OW;
+            bool eq = true;
+#pragma unroll
+            for (int q = 0; q < OW; ++q) eq = eq && dk[q] == w[q];
+            if (eq) { v = db_dns[r]; break; }
+            h = (h + 1) & tmask;
+        }
+        out[i] = v;
     }
 }
 

@@ -147,6 +147,78 @@ def test_nsqmain_reference_defaults_vs_fixture(engine, nsq_fixture):
         assert len(r.beta_history) == 10 and r.beta_history[-1] == r.current_beta
 
 
+def test_nsqmain_with_the_references_batch_of_100(engine):
+    """The reference's literal loop (100 samples per checkpoint, nsqMain.m:60): the library evaluates many checkpoints
+    per launch and derives each checkpoint's indices from the per-sample dns.  Checked against (a) the histories built
+    from mc_sampling + mc_simulation of the same samples, (b) the accumulators of one nsq_accumulate over the same range,
+    (c) the same run with a batch too large for that path (one launch per checkpoint)."""
+    n, b, seed = 100000, 100, 7
+    r = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=b, seed=seed)
+    assert r.current_iteration == n and len(r.beta_history) == n // b and not r.converged
+    st = engine.mc_sampling(None, n, seed=seed, first_index=0)
+    dns, _ = engine.mc_simulation(st)
+    k = np.arange(1, n // b + 1) * b
+    cs, cs2, cf = np.cumsum(dns)[k - 1], np.cumsum(dns * dns)[k - 1], np.cumsum(dns > 1e-4)[k - 1]
+    edns = cs / k
+    np.testing.assert_allclose(r.edns_history, edns, rtol=1e-11)
+    np.testing.assert_allclose(r.plc_history, cf / k, rtol=0, atol=1e-15)
+    np.testing.assert_allclose(r.lole_history, cf / k * 8760.0, rtol=1e-14)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        beta = np.where(edns > 0, np.sqrt(np.maximum(cs2 - k * edns * edns, 0.0)) / k / edns, np.inf)
+    np.testing.assert_allclose(r.beta_history, beta, rtol=1e-9)
+    whole = engine.nsq_accumulate(seed, 0, n)
+    wi, wd = whole.to_arrays(); ri, rd = r.acc.to_arrays()
+    assert np.array_equal(wi, ri)
+    np.testing.assert_allclose(rd, wd, rtol=1e-11, atol=1e-9)
+    # a run that stops inside a stretch ends at the checkpoint the batch-by-batch loop ends at, with that range's accumulators
+    r2 = engine.nsqMain(beta_limit=0.05, max_iterations=n, samples_per_batch=b, seed=seed)
+    m = r2.current_iteration
+    assert r2.converged and m % b == 0 and 0 < m < n and len(r2.beta_history) == m // b
+    assert r2.beta_history[-1] <= 0.05 and np.all(r2.beta_history[:-1] > 0.05)
+    np.testing.assert_allclose(r2.beta_history, r.beta_history[:m // b], rtol=1e-12)
+    cut = engine.nsq_accumulate(seed, 0, m)
+    ci, cd = cut.to_arrays(); ri, rd = r2.acc.to_arrays()
+    assert np.array_equal(ci, ri)
+    np.testing.assert_allclose(rd, cd, rtol=1e-11, atol=1e-9)
+    assert r2.current_beta == r2.beta_history[-1] and r.current_beta == r.beta_history[-1]
+    # ragged tail: the last checkpoint holds fewer samples than a batch
+    r3 = engine.nsqMain(beta_limit=0.0, max_iterations=30050, samples_per_batch=b, seed=seed)
+    assert r3.current_iteration == 30050 and len(r3.beta_history) == 301
+    np.testing.assert_allclose(r3.beta_history[:300], r.beta_history[:300], rtol=1e-12)
+    t = engine.nsq_accumulate(seed, 0, 30050)
+    assert np.array_equal(t.to_arrays()[0], r3.acc.to_arrays()[0])
+    # the reference's own form of the loop (unique-state database, nsqMain.m:220-278) with its batch of 100
+    d = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=b, seed=seed, distinct_states="database")
+    assert d.current_iteration == n and len(d.beta_history) == n // b
+    for h in ("beta_history", "edns_history", "lole_history", "plc_history"):
+        np.testing.assert_allclose(getattr(d, h), getattr(r, h), rtol=1e-9)
+    assert np.array_equal(d.acc.to_arrays()[0], whole.to_arrays()[0])
+    assert d.current_beta == d.beta_history[-1]
+    # ... stopping inside a stretch leaves the database of exactly the samples drawn: rows, their order and their counts
+    d2 = engine.nsqMain(beta_limit=0.05, max_iterations=n, samples_per_batch=b, seed=seed, distinct_states="database")
+    assert d2.converged and d2.current_iteration == m and len(d2.beta_history) == m // b
+    assert np.array_equal(d2.acc.to_arrays()[0], cut.to_arrays()[0])
+    got = engine.db_export()
+    assert engine.db_size() == (d2.database_row_count, m) and got["count"].sum() == m
+    engine.db_reset()
+    engine.nsq_db_batch(seed, 0, m)
+    want = engine.db_export()
+    for key in ("states", "count", "dns", "status", "iters"):
+        assert np.array_equal(got[key], want[key]), key
+    # ... also when the stretch that is cut short started from a filled database (rows and counts put back first)
+    d3 = engine.nsqMain(beta_limit=0.007, max_iterations=1_000_000, samples_per_batch=b, seed=seed, distinct_states="database")
+    m3 = d3.current_iteration
+    assert d3.converged and m3 > 262_100 and m3 % b == 0 and d3.beta_history[-2] > 0.007 >= d3.beta_history[-1]
+    got = engine.db_export()
+    engine.db_reset()
+    engine.nsq_db_batch(seed, 0, m3)
+    want = engine.db_export()
+    for key in ("states", "count", "dns", "status", "iters"):
+        assert np.array_equal(got[key], want[key]), key
+    assert np.array_equal(d3.acc.to_arrays()[0], engine.nsq_accumulate(seed, 0, m3).to_arrays()[0])
+    engine.db_reset()
+
+
 def test_full_size_properties(engine, golden):
     """BASELINE config 2 (1e6 samples) through size-independent properties + the reference's golden run."""
     n = 1_000_000
