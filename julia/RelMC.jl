@@ -47,6 +47,29 @@ mutable struct Indices
     Indices() = new()
 end
 
+"isbits image of relmc_solver_opts, for embedding in NsqOpts"
+struct SolverOptsC
+    singular_policy::Int32; max_it::Int32
+    feastol::Cdouble; gradtol::Cdouble; comptol::Cdouble; costtol::Cdouble
+    xi::Cdouble; sigma::Cdouble; z0::Cdouble; alpha_min::Cdouble; max_stepsize::Cdouble
+end
+SolverOptsC(o::SolverOpts) = SolverOptsC(o.singular_policy, o.max_it, o.feastol, o.gradtol, o.comptol, o.costtol, o.xi, o.sigma, o.z0,
+                                         o.alpha_min, o.max_stepsize)
+
+"relmc_nsq_opts (include/relmc.h): the options of the whole nsqMain loop"
+struct NsqOpts
+    beta_limit::Cdouble; max_samples::Int64; batch::Int64; seed::UInt64; hours_per_year::Cdouble
+    solver::SolverOptsC
+    history_cap::Int64
+    beta_history::Ptr{Cdouble}; edns_history::Ptr{Cdouble}; lole_history::Ptr{Cdouble}; plc_history::Ptr{Cdouble}
+    distinct_states::Int32
+end
+
+# relmc_nsq_result is read out of a byte buffer at these offsets (Acc and Indices are mutable mirrors and cannot be embedded)
+const NSQ_RESULT_BYTES = 8 * (6 + MAX_COMP + 2 + MAX_BUS) + 8 * (7 + MAX_BUS + MAX_COMP) + 40
+const NSQ_RESULT_IDX = 8 * (6 + MAX_COMP + 2 + MAX_BUS)
+const NSQ_RESULT_TAIL = NSQ_RESULT_IDX + 8 * (7 + MAX_BUS + MAX_COMP)     # checkpoints, converged, wall_seconds, kernel_seconds, batches
+
 "TestSystem after the load model of nsqMain.m:121-153 (0-based indices inside)."
 struct TestSystem
     base_mva::Float64; nb::Int; ng::Int; nl::Int; nd::Int; ref_bus::Int
@@ -143,6 +166,12 @@ struct DbStats
 end
 
 db_reset(eng::Engine) = check(ccall((:relmc_db_reset, LIB), Int32, (Ptr{Cvoid},), eng.h), eng.h, "relmc_db_reset")
+"(rows, samples) of the state database"
+function db_size(eng::Engine)
+    rows = Ref{Int64}(0); samples = Ref{Int64}(0)
+    check(ccall((:relmc_db_size, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), eng.h, rows, samples), eng.h, "relmc_db_size")
+    return (rows[], samples[])
+end
 
 "One pass of the loop body (dedupe, count bumps of known states, evaluation of the new ones, indices from ALL rows): (Acc of the whole database, DbStats)."
 function nsq_db_batch(eng::Engine, seed::Integer, first_index::Integer, n::Integer, mpopt::SolverOpts=mpoption())
@@ -188,9 +217,35 @@ function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples
     total = Acc(); ccall((:relmc_acc_zero, LIB), Cvoid, (Ref{Acc},), total)
     done = 0; beta = Inf; idx = Indices(); rows = 0
     beta_history = Float64[]; edns_history = Float64[]; lole_history = Float64[]; plc_history = Float64[]
-    distinct_states === :database && db_reset(eng)
     t0 = time()
-    while beta > beta_limit && done < max_iterations
+    if nranks == 1
+        # one rank: the loop runs inside the library (relmc_nsq_run), which evaluates small batches such as the reference's
+        # 100 many checkpoints per launch (DESIGN.md 6.8); histories and stopping point are those of the loop below
+        ncp = cld(max_iterations, samples_per_batch)
+        beta_history = zeros(ncp); edns_history = zeros(ncp); lole_history = zeros(ncp); plc_history = zeros(ncp)
+        mode = distinct_states === :database ? 2 : (distinct_states === true ? 1 : 0)
+        buf = zeros(UInt8, NSQ_RESULT_BYTES)
+        GC.@preserve beta_history edns_history lole_history plc_history buf total idx begin
+            o = NsqOpts(beta_limit, max_iterations, samples_per_batch, seed, 8760.0, SolverOptsC(mpopt), ncp, pointer(beta_history),
+                        pointer(edns_history), pointer(lole_history), pointer(plc_history), mode)
+            check(ccall((:relmc_nsq_run, LIB), Int32, (Ptr{Cvoid}, Ref{NsqOpts}, Ptr{UInt8}), eng.h, Ref(o), buf), eng.h, "relmc_nsq_run")
+            unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(total)), pointer(buf), NSQ_RESULT_IDX)
+            unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(idx)), pointer(buf) + NSQ_RESULT_IDX, NSQ_RESULT_TAIL - NSQ_RESULT_IDX)
+            k = unsafe_load(Ptr{Int64}(pointer(buf) + NSQ_RESULT_TAIL))
+        end
+        resize!(beta_history, k); resize!(edns_history, k); resize!(lole_history, k); resize!(plc_history, k)
+        done = idx.n; beta = idx.beta
+        mode == 2 && (rows = db_size(eng)[1])
+        if verbose
+            for c in 1:k
+                n_c = min(c * samples_per_batch, done)
+                n_c % 1000 == 0 && println("Iteration ", lpad(n_c, 6), ": Beta = ", round(beta_history[c], digits=6), ", EDNS = ",
+                                           round(edns_history[c], digits=4), " MW, LOLE = ", round(lole_history[c], digits=4), " hr/yr")
+            end
+        end
+    end
+    nranks > 1 && distinct_states === :database && db_reset(eng)
+    while nranks > 1 && beta > beta_limit && done < max_iterations
         m = min(samples_per_batch, max_iterations - done)
         lo = done + div(m * rank, nranks); cnt = done + div(m * (rank + 1), nranks) - lo       # contiguous slice of the batch
         if distinct_states === :database
@@ -327,6 +382,8 @@ const LAYOUT = [
     ("relmc_db_stats", 32, [("rows", 0), ("samples", 8), ("new_rows", 16), ("batch_distinct", 24)]),
     ("relmc_seq_year", 32, [("ens", 0), ("dlc", 8), ("nlc", 16), ("n_contingency", 24)]),
     ("relmc_hl1_acc", 40, [("n", 0), ("sum_lole", 8), ("sum_eue2", 32)]),
+    ("relmc_nsq_opts", 168, [("beta_limit", 0), ("max_samples", 8), ("batch", 16), ("seed", 24), ("hours_per_year", 32), ("solver", 40), ("history_cap", 120), ("beta_history", 128), ("plc_history", 152), ("distinct_states", 160)]),
+    ("relmc_nsq_result", NSQ_RESULT_BYTES, [("acc", 0), ("idx", NSQ_RESULT_IDX), ("checkpoints", NSQ_RESULT_TAIL), ("converged", NSQ_RESULT_TAIL + 8), ("wall_seconds", NSQ_RESULT_TAIL + 16), ("kernel_seconds", NSQ_RESULT_TAIL + 24), ("batches", NSQ_RESULT_TAIL + 32)]),
 ]
 
 end # module

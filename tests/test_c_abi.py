@@ -61,19 +61,21 @@ def test_struct_layouts_match_the_mirrors(tmp_path):
     block = jl[jl.index("const LAYOUT = ["):]
     block = block[:block.index("\n]\n") + 3]
     consts = dict(MAX_COMP=256, MAX_BUS=128)
+    for m in re.finditer(r'^const (NSQ_RESULT_\w+) = (.+?)(?:#.*)?$', jl, re.M):        # derived offsets of relmc_nsq_result
+        consts[m.group(1)] = int(eval(m.group(2), {}, consts))
     table = []
     for m in re.finditer(r'\("(relmc_\w+)",\s*([^,\[]+),\s*\[(.*?)\]\)', block):
         fields = [(f, int(eval(off, {}, consts))) for f, off in re.findall(r'\("(\w+)",\s*([^)]+)\)', m.group(3))]
         table.append((m.group(1), int(eval(m.group(2), {}, consts)), fields))
-    assert len(table) == 7
+    assert len(table) == 9
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "relmc.h"', 'int main(void) {']
     for name, _, fields in table:
         prog.append(f'printf("{name} %zu", sizeof({name}));')
         for f, _ in fields:
             prog.append(f'printf(" %zu", offsetof({name}, {f}));')
         prog.append('printf("\\n");')
-    prog += ['printf("relmc_nsq_opts %zu %zu %zu\\n", sizeof(relmc_nsq_opts), offsetof(relmc_nsq_opts, solver), offsetof(relmc_nsq_opts, distinct_states));',
-             'printf("relmc_nsq_result %zu %zu %zu\\n", sizeof(relmc_nsq_result), offsetof(relmc_nsq_result, checkpoints), offsetof(relmc_nsq_result, batches));',
+    prog += ['printf("py_nsq_opts %zu %zu %zu\\n", sizeof(relmc_nsq_opts), offsetof(relmc_nsq_opts, solver), offsetof(relmc_nsq_opts, distinct_states));',
+             'printf("py_nsq_result %zu %zu %zu\\n", sizeof(relmc_nsq_result), offsetof(relmc_nsq_result, checkpoints), offsetof(relmc_nsq_result, batches));',
              'return 0; }']
     src = tmp_path / "layout.c"
     src.write_text("\n".join(prog))
@@ -89,5 +91,5 @@ def test_struct_layouts_match_the_mirrors(tmp_path):
             assert C.sizeof(mirror[name]) == size, name
             for f, off in fields:
                 assert getattr(mirror[name], f).offset == off, (name, f)
-    assert got["relmc_nsq_opts"] == [C.sizeof(_abi.NsqOpts), _abi.NsqOpts.solver.offset, _abi.NsqOpts.distinct_states.offset]
-    assert got["relmc_nsq_result"] == [C.sizeof(_abi.NsqResult), _abi.NsqResult.checkpoints.offset, _abi.NsqResult.batches.offset]
+    assert got["py_nsq_opts"] == [C.sizeof(_abi.NsqOpts), _abi.NsqOpts.solver.offset, _abi.NsqOpts.distinct_states.offset]
+    assert got["py_nsq_result"] == [C.sizeof(_abi.NsqResult), _abi.NsqResult.checkpoints.offset, _abi.NsqResult.batches.offset]
