@@ -985,6 +985,14 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     SLOT_FENCE();
                 }
                 step2 = row_sum<RW>(step2);
+#ifdef RELMC_TRACE
+                if (a.timing && blockIdx.x == 0 && tid < RW && it < 40) {     // debug builds: the Newton step of scenario 0, per iteration
+                    double* o2 = reinterpret_cast<double*>(a.timing) + 512 + 512 * it;
+                    for (int t = 0; t < BS; ++t) { o2[RW * t + rlane] = dth[t]; o2[128 + RW * t + rlane] = dla[t]; }
+                    for (int s = 0; s < IS; ++s) o2[256 + RW * s + rlane] = dpv[s];
+                    if (it == 1) for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) (reinterpret_cast<double*>(a.timing) + 512 + 512 * 40)[RW * t + rlane] = (double)C.b_ext[RW * t + rlane];
+                }
+#endif
 #ifdef RELMC_ABLATE_FIXIT
                 if (false) {
 #else
