@@ -166,6 +166,12 @@ struct DbStats
 end
 
 db_reset(eng::Engine) = check(ccall((:relmc_db_reset, LIB), Int32, (Ptr{Cvoid},), eng.h), eng.h, "relmc_db_reset")
+"(units evaluated a second time under the alternate elimination order, how many of them then converged) since the case was loaded"
+function retry_stats(eng::Engine)
+    u = Ref{Int64}(0); c = Ref{Int64}(0)
+    check(ccall((:relmc_retry_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), eng.h, u, c), eng.h, "relmc_retry_stats")
+    return (u[], c[])
+end
 "(rows, samples) of the state database"
 function db_size(eng::Engine)
     rows = Ref{Int64}(0); samples = Ref{Int64}(0)

@@ -273,6 +273,13 @@ class Engine:
         self._check(self.L.relmc_db_size(self._h, C.byref(rows), C.byref(samples)), "relmc_db_size")
         return int(rows.value), int(samples.value)
 
+    def retry_stats(self):
+        """(units evaluated a second time under the alternate elimination order, how many of them then converged) since the
+        case was loaded (relmc_retry_stats)."""
+        u, c = C.c_int64(), C.c_int64()
+        self._check(self.L.relmc_retry_stats(self._h, C.byref(u), C.byref(c)), "relmc_retry_stats")
+        return int(u.value), int(c.value)
+
     def db_export(self, first_row: int = 0, n_rows: int | None = None) -> dict:
         """Rows of the database in the reference's column layout (nsqMain.m:91-99): states, count, dns, flag, nodal
         (+ solver status and iteration count)."""

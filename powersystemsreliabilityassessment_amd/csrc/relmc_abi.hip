@@ -8,6 +8,7 @@
 #include <cmath>
 #include <cstdio>
 #include <cstring>
+#include <memory>
 #include <new>
 #include <string>
 #include <thread>
@@ -54,6 +55,18 @@ struct relmc_ctx {
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
     double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
     bool db_has_opts = false; relmc_solver_opts db_opts;
+    // retry of the units the primary elimination order does not converge on: a second device image of the case built with
+    // another static order (lazily, from a copy of the description), the kernel's list of such units, scratch rows for their re-evaluation
+    struct CaseCopy {
+        relmc_case_desc d; bool valid = false;
+        std::vector<double> bus_pd, inj_pmin, inj_pmax, inj_cost, br_b, br_rate, unavail; std::vector<int32_t> inj_bus, br_from, br_to; std::vector<uint8_t> always_up;
+    } case_copy;
+    static constexpr int kAlt = 2;           // further static orders: [0] the primary rule with the ties broken the other way, [1] fill first
+    int alt_state[kAlt] = {0, 0};            // 0 not built yet, 1 ready, -1 unavailable (that order does not fit the tile)
+    void* dcase_alt[kAlt] = {nullptr, nullptr}; uint32_t alt_scen_doubles[kAlt] = {0, 0}, alt_lds_bytes[kAlt] = {0, 0}, alt_stash_off[kAlt] = {0, 0};
+    FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr;
+    uint32_t* rkeys = nullptr; double* rdns = nullptr; int32_t* rmeta = nullptr; double* rnodal = nullptr; double* rscale = nullptr; int64_t rcap = 0;
+    int64_t retry_units = 0, retry_converged = 0;        // since the case was loaded
     unsigned long long* db_snap = nullptr; int64_t db_snap_cap = 0;      // row counts before a stretch of small batches (relmc_nsq_run)
     // host-buffer entry points (relmc_mc_simulation, relmc_seq_mcsimulation): double-buffered chunk pipeline, device buffers
     // and pinned staging kept across calls
@@ -130,16 +143,16 @@ int ensure_partial(relmc_ctx* ctx, size_t bytes)
 
 // launches the evaluation kernel of the active tile; *rows_out = scenario rows holding partial accumulators
 template <int MODE, class TL>
-int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int alt = 0)
 {
     const int blocks = grid_for<TL>(ctx, a.n);
     int rc = ensure_partial(ctx, sizeof(PartialT<TL>) * 64 * TL::WPB * (size_t)blocks);
     if (rc) return rc;
     a.partial = ctx->dpartial;
-    a.scen_doubles = ctx->scen_doubles;
+    a.scen_doubles = alt ? ctx->alt_scen_doubles[alt - 1] : ctx->scen_doubles;
     // the grid fills the device: first-dispatched and later wavefronts share every SIMD (see the kernel's priority balancing)
     a.prio_mode = blocks != ctx->num_cu * ctx->blocks_per_cu ? 0u : (ctx->blocks_per_cu == 2 ? 1u : (ctx->blocks_per_cu == 1 && TL::WPB == 8 ? 2u : 0u));
-    a.stash_off = ctx->stash_off;
+    a.stash_off = alt ? ctx->alt_stash_off[alt - 1] : ctx->stash_off;
 #if defined(RELMC_PHASE_TIMING) || defined(RELMC_TRACE)
     if (!ctx->dtiming) HIP_TRY(ctx, hipMalloc(&ctx->dtiming, sizeof(unsigned long long) * 8 * 65536));
     a.timing = ctx->dtiming; ctx->timing_waves = blocks * TL::WPB;
@@ -147,8 +160,8 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_star
     a.timing = nullptr;
 #endif
     HIP_TRY(ctx, hipEventRecord(ev_start ? ev_start : ctx->ev0, ctx->stream));
-    hipLaunchKernelGGL((relmc_eval_kernel<MODE, TL>), dim3(blocks), dim3(64 * TL::WPB), ctx->lds_bytes, ctx->stream,
-                       reinterpret_cast<const DevCaseT<TL>*>(ctx->dcase), a);
+    hipLaunchKernelGGL((relmc_eval_kernel<MODE, TL>), dim3(blocks), dim3(64 * TL::WPB), alt ? ctx->alt_lds_bytes[alt - 1] : ctx->lds_bytes, ctx->stream,
+                       reinterpret_cast<const DevCaseT<TL>*>(alt ? ctx->dcase_alt[alt - 1] : ctx->dcase), a);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipEventRecord(ev_stop ? ev_stop : ctx->ev1, ctx->stream));
     *rows_out = blocks * TL::WPB * TL::SPW;
@@ -156,10 +169,10 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_star
 }
 
 template <int MODE>
-int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr)
+int launch_eval(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int alt = 0)
 {
-    if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out, ev_start, ev_stop);
-    return launch_eval_t<MODE, Tile96>(ctx, a, rows_out, ev_start, ev_stop);
+    if (ctx->tile == 0) return launch_eval_t<MODE, Tile24>(ctx, a, rows_out, ev_start, ev_stop, alt);
+    return launch_eval_t<MODE, Tile96>(ctx, a, rows_out, ev_start, ev_stop, alt);
 }
 
 // deterministic reduction of the partial records into the device image of relmc_acc
@@ -189,8 +202,9 @@ int finish_timing(relmc_ctx* ctx)
 // static task schedule the kernel interprets, incidence lists, thresholds.  Mirrors what
 // nsqMain.m:42-167 prepares once before its Monte Carlo loop.
 template <class TL>
-int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
+int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant = 0)
 {
+    const bool alt = order_variant != 0;            // the alternate image: geometry into the alt_* fields, nothing else of the context changes
     constexpr int NBT = TL::NBT, NLT = TL::NLT, NIT = TL::NIT, NCOMPMAX = TL::NCOMPMAX, MAXOFF = TL::MAXOFF, MAXPASS = TL::MAXPASS,
                   ROWL = TL::RW, IS = TL::IS, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     const int nb = d->nb, ng = d->ng, nl = d->nl, nd = d->nd, ninj = ng + nd, ncomp = ng + nl;
@@ -224,7 +238,10 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
                 for (int y = x + 1; y < nb; ++y) if (!gone[y] && y != b && A[b][y] && !A[x][y]) fillc++;
             }
             // shallow elimination tree first (fewer dependent passes), then little fill
-            const long key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + b;
+            long key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + b;
+            if (order_variant == 1) key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + (nb - 1 - b);       // other tie-breaks
+            else if (order_variant == 2) key = ((long)fillc * 1000 + lev) * 10000 + deg * 100 + b;            // fill first;
+
             if (best < 0 || key < bestkey) { best = b; bestkey = key; }
         }
         int lev = 0;
@@ -569,14 +586,25 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     const uint32_t eval_doubles = 4u * (nl + 1) + 4u * (ninj + 1);   // line / injection records (+1 zero record each): alias the workspace
     uint32_t scen = C.nws > eval_doubles ? C.nws : eval_doubles;
     scen = (scen + 1u) & ~1u;
-    ctx->stash_off = scen;
+    const uint32_t stash_off = scen;
     scen += 2u * IS * ROWL + NBT + OW / 2u;                // stash: 1/D and Np/D per injection lane; lambda per bus; outage mask words
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
-    ctx->scen_doubles = scen;
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
-    ctx->lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
+    const uint32_t lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    if (ctx->lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
+    if (lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
+    if (alt) {
+        const int v = order_variant - 1;
+        if (!ctx->dcase_alt[v]) HIP_TRY(ctx, hipMalloc(&ctx->dcase_alt[v], sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)));
+        ctx->alt_stash_off[v] = stash_off; ctx->alt_scen_doubles[v] = scen; ctx->alt_lds_bytes[v] = lds_bytes;
+        uint32_t most = ctx->lds_bytes;
+        for (int q = 0; q < relmc_ctx::kAlt; ++q) if (ctx->alt_lds_bytes[q] > most) most = ctx->alt_lds_bytes[q];
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
+        HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase_alt[v], &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
+        HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+        return RELMC_OK;
+    }
+    ctx->stash_off = stash_off; ctx->scen_doubles = scen; ctx->lds_bytes = lds_bytes;
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
@@ -595,6 +623,143 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C)
     return RELMC_OK;
 }
 
+
+// ---- second chance for the units the primary elimination order does not converge on ---------------------------------------------
+// The block elimination runs in an order fixed per case; on a few states (6.7e-7 of the RTS-96 scenarios, 4e-10 on RTS-24) that order
+// meets a stiff line next to a bus with an interior injection and the Newton steps of the last iterations lose their digits (DESIGN.md
+// 6.3).  Which states depends on the order: of the 67 such RTS-96 states in 1e8 samples, 66 converge under the same elimination rule with
+// the ties broken the other way (same pass counts).  The kernel lists the units it ends non-converged instead of accumulating them; they
+// are evaluated again here under that second order and their results take the place of the first attempt's.
+constexpr uint32_t kFailCap = 4096;
+
+struct RetryOut { std::vector<FailRec> rec; std::vector<double> dns, nodal; std::vector<int32_t> meta; };   // meta = status | relaxed << 2 | iterations << 8
+
+int alt_ensure(relmc_ctx* ctx, int v)          // v = 0, 1: which further order
+{
+    if (ctx->alt_state[v]) return ctx->alt_state[v] > 0 ? RELMC_OK : RELMC_ERR_UNSUPPORTED;
+    ctx->alt_state[v] = -1;
+    if (!ctx->case_copy.valid) return RELMC_ERR_UNSUPPORTED;
+    const std::string keep = ctx->err;
+    int rc;
+    if (ctx->tile == 0) { auto C = std::make_unique<DevCaseT<Tile24>>(); rc = case_load_impl<Tile24>(ctx, &ctx->case_copy.d, *C, v + 1); }
+    else { auto C = std::make_unique<DevCaseT<Tile96>>(); rc = case_load_impl<Tile96>(ctx, &ctx->case_copy.d, *C, v + 1); }
+    ctx->err = keep;                               // a case whose further order does not fit simply has one attempt less
+    if (rc == RELMC_OK) ctx->alt_state[v] = 1;
+    return rc;
+}
+
+// arms the kernel's list for the next launch(es); `reset` zeroes the count (first launch of a call)
+int fail_arm(relmc_ctx* ctx, EvalArgs& a, int64_t unit_base, bool reset)
+{
+    a.fail_list = nullptr; a.fail_count = nullptr; a.fail_cap = 0; a.unit_base = unit_base;
+    static const bool off = getenv("RELMC_NO_RETRY") != nullptr;      // diagnosis: the first attempt's results as they are
+    if (off || (ctx->alt_state[0] < 0 && ctx->alt_state[1] < 0)) return RELMC_OK;
+    if (!ctx->dfail) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * kFailCap));
+        HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail, 0, sizeof(FailRec) * kFailCap, ctx->stream));
+        reset = true;
+    }
+    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
+    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap;
+    return RELMC_OK;
+}
+
+// After the launches of a call have completed: the listed units (ascending), evaluated under the second order.  `scale` (optional) maps a
+// unit to its load scale factor.  out.rec is empty when nothing was listed.  Adds the retry kernel's time to *ms.
+template <class ScaleFn>
+int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold, ScaleFn scale, bool have_scale, RetryOut& out, double* ms)
+{
+    out.rec.clear();
+    if (!ctx->dfail_count) return RELMC_OK;
+    uint32_t cnt = 0;
+    HIP_TRY(ctx, hipMemcpy(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (cnt == 0) return RELMC_OK;
+    if (cnt > kFailCap) cnt = kFailCap;                      // the units beyond the list were accumulated by the kernel as they were
+    out.rec.resize(cnt);
+    HIP_TRY(ctx, hipMemcpy(out.rec.data(), ctx->dfail, sizeof(FailRec) * cnt, hipMemcpyDeviceToHost));
+    std::sort(out.rec.begin(), out.rec.end(), [](const FailRec& x, const FailRec& y) { return x.unit < y.unit; });
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const size_t nb = (size_t)ctx->nb;
+    if ((int64_t)cnt > ctx->rcap) {
+        for (void* p : {(void*)ctx->rkeys, (void*)ctx->rdns, (void*)ctx->rmeta, (void*)ctx->rnodal, (void*)ctx->rscale}) if (p) (void)hipFree(p);
+        ctx->rkeys = nullptr; ctx->rdns = nullptr; ctx->rmeta = nullptr; ctx->rnodal = nullptr; ctx->rscale = nullptr; ctx->rcap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->rkeys, sizeof(uint32_t) * kFailCap * 8));
+        HIP_TRY(ctx, hipMalloc(&ctx->rdns, sizeof(double) * kFailCap));
+        HIP_TRY(ctx, hipMalloc(&ctx->rmeta, sizeof(int32_t) * kFailCap));
+        HIP_TRY(ctx, hipMalloc(&ctx->rnodal, sizeof(double) * kFailCap * RELMC_MAX_BUS));
+        HIP_TRY(ctx, hipMalloc(&ctx->rscale, sizeof(double) * kFailCap));
+        ctx->rcap = kFailCap;
+    }
+    std::vector<uint32_t> keys((size_t)cnt * ow);
+    for (uint32_t r = 0; r < cnt; ++r) for (int q = 0; q < ow; ++q) keys[(size_t)r * ow + q] = out.rec[r].mask[q];
+    HIP_TRY(ctx, hipMemcpy(ctx->rkeys, keys.data(), sizeof(uint32_t) * keys.size(), hipMemcpyHostToDevice));
+    if (have_scale) {
+        std::vector<double> sc(cnt);
+        for (uint32_t r = 0; r < cnt; ++r) sc[r] = scale(out.rec[r].unit);
+        HIP_TRY(ctx, hipMemcpy(ctx->rscale, sc.data(), sizeof(double) * cnt, hipMemcpyHostToDevice));
+    }
+    out.dns.resize(cnt); out.meta.resize(cnt); out.nodal.resize((size_t)cnt * nb);
+    // first the whole list under the second order, then whatever is still non-converged under the third (the sets of states the three
+    // orders fail on were disjoint on the 67 RTS-96 states of the fixture).  A case without further orders (they do not fit the tile)
+    // repeats the primary one, so that the callers' bookkeeping is one path.
+    for (int level = 0; level < relmc_ctx::kAlt; ++level) {
+        const bool have = alt_ensure(ctx, level) == RELMC_OK;
+        if (level > 0 && !have) break;
+        EvalArgs a = make_args(o);
+        a.fail_threshold = fail_threshold;
+        a.load_scale = have_scale ? ctx->rscale : nullptr;
+        int rows = 0, rc;
+        if (level == 0) {
+            a.n = (int64_t)cnt; a.memo_keys = ctx->rkeys; a.db_first = 0; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
+            rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, have ? 1 : 0);
+            if (rc) return rc;
+            const double before = ctx->last_kernel_ms;
+            rc = finish_timing(ctx);
+            if (rc) return rc;
+            if (ms) *ms += ctx->last_kernel_ms;
+            ctx->last_kernel_ms = before;
+            HIP_TRY(ctx, hipMemcpy(out.meta.data(), ctx->rmeta, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+        } else {
+            for (uint32_t r = 0; r < cnt; ++r) {
+                if ((out.meta[r] & 3) != 1 && (out.meta[r] & 3) != 2) continue;
+                a.n = 1; a.memo_keys = ctx->rkeys; a.db_first = (int64_t)r; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
+                a.load_scale = have_scale ? ctx->rscale + r : nullptr;
+                rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, level + 1);
+                if (rc) return rc;
+                const double before = ctx->last_kernel_ms;
+                rc = finish_timing(ctx);
+                if (rc) return rc;
+                if (ms) *ms += ctx->last_kernel_ms;
+                ctx->last_kernel_ms = before;
+            }
+        }
+    }
+    HIP_TRY(ctx, hipMemcpy(out.dns.data(), ctx->rdns, sizeof(double) * cnt, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out.meta.data(), ctx->rmeta, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+    HIP_TRY(ctx, hipMemcpy(out.nodal.data(), ctx->rnodal, sizeof(double) * cnt * nb, hipMemcpyDeviceToHost));
+    ctx->retry_units += cnt;
+    for (uint32_t r = 0; r < cnt; ++r) if ((out.meta[r] & 3) == 0 || (out.meta[r] & 3) == 3) ctx->retry_converged += 1;
+    return RELMC_OK;
+}
+inline double no_scale(unsigned long long) { return 1.0; }
+
+// the accumulators of one unit (what the kernel's output section adds for it), count-weighted
+void acc_add_unit(relmc_acc* acc, const FailRec& rec, double dns, int32_t meta, const double* nodal, int nb, int ncomp, double fail_threshold)
+{
+    const long long w = (long long)rec.weight;
+    const int status = meta & 3, it = (int)((uint32_t)meta >> 8);
+    const bool fail = dns > fail_threshold;
+    acc->n += w;
+    if (fail) acc->n_fail += w;
+    if (status == 3) acc->n_singular += w;
+    if (status == 1 || status == 2) acc->n_nonconverged += w;
+    if (meta & 4) acc->n_infeasible += w;
+    acc->sum_iters += (long long)it * w;
+    if (dns != 0.0) { acc->sum_dns += (double)w * dns; acc->sum_dns2 += (double)w * dns * dns; }
+    if (fail) for (int k = 0; k < ncomp; ++k) if ((rec.mask[k >> 5] >> (k & 31)) & 1u) acc->comp_fail[k] += w;
+    for (int i = 0; i < nb; ++i) acc->sum_nodal[i] += (double)w * nodal[i];
+}
 
 // ---- host-buffer evaluation: states in pageable host memory -> dns / nodal / status / iterations in host memory ---------
 // What a MATLAB / Julia / Python caller of mc_simulation hands over.  The range is cut into chunks of kPipeChunk states that
@@ -688,6 +853,8 @@ int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, in
         a.n = m; a.states = P.d_st[b]; a.load_scale = load_scale ? P.d_sc[b] : nullptr;
         a.dns = P.d_dns[b]; a.nodal = nodal ? P.d_nod[b] : nullptr; a.status = status ? P.d_stat[b] : nullptr; a.iters = iters ? P.d_it[b] : nullptr;
         int rows = 0;
+        rc = fail_arm(ctx, a, lo, k == 0);
+        if (rc) return rc;
         rc = launch_eval<1>(ctx, a, &rows, P.e_ks[b], P.e_ke[b]);
         if (rc) return rc;
         HIP_TRY(ctx, hipStreamWaitEvent(P.down, P.e_ke[b], 0));
@@ -698,6 +865,17 @@ int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, in
         HIP_TRY(ctx, hipEventRecord(P.e_down[b], P.down));
     }
     for (int64_t k = nchunk >= 2 ? nchunk - 2 : 0; k < nchunk; ++k) { rc = drain(k); if (rc) return rc; }
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    RetryOut ro;
+    rc = fail_retry(ctx, o, fail_threshold, [&](unsigned long long u) { return load_scale ? load_scale[u] : 1.0; }, load_scale != nullptr, ro, &kernel_ms);
+    if (rc) return rc;
+    for (size_t r = 0; r < ro.rec.size(); ++r) {              // the second attempt's results in the place of the first's
+        const size_t u = (size_t)ro.rec[r].unit;
+        dns[u] = ro.dns[r];
+        if (nodal) std::memcpy(nodal + u * nb, &ro.nodal[r * nb], sizeof(double) * nb);
+        if (status) status[u] = ro.meta[r] & 3;
+        if (iters) iters[u] = (int32_t)((uint32_t)ro.meta[r] >> 8);
+    }
     ctx->last_kernel_ms = kernel_ms;
     return RELMC_OK;
 }
@@ -751,6 +929,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
     if (ctx->dhist) (void)hipFree(ctx->dhist);
     if (ctx->hhist) (void)hipHostFree(ctx->hhist);
+    for (void* p : {ctx->dcase_alt[0], ctx->dcase_alt[1], (void*)ctx->dfail, (void*)ctx->dfail_count, (void*)ctx->rkeys, (void*)ctx->rdns, (void*)ctx->rmeta, (void*)ctx->rnodal, (void*)ctx->rscale}) if (p) (void)hipFree(p);
     comm_free(ctx);
     pipe_free(ctx);
     db_free(ctx);
@@ -796,6 +975,20 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: inconsistent sizes");
     ctx->has_case = false;
     db_free(ctx);                  // the state database belongs to the case it was filled for
+    {   // the description is kept: the second elimination order (retry of non-converged units) is built from it when first needed
+        auto& cc = ctx->case_copy;
+        const int ninj = ng + nd, ncomp = ng + nl;
+        cc.bus_pd.assign(d->bus_pd, d->bus_pd + nb); cc.inj_bus.assign(d->inj_bus, d->inj_bus + ninj);
+        cc.inj_pmin.assign(d->inj_pmin, d->inj_pmin + ninj); cc.inj_pmax.assign(d->inj_pmax, d->inj_pmax + ninj); cc.inj_cost.assign(d->inj_cost, d->inj_cost + ninj);
+        cc.br_from.assign(d->br_from, d->br_from + nl); cc.br_to.assign(d->br_to, d->br_to + nl); cc.br_b.assign(d->br_b, d->br_b + nl); cc.br_rate.assign(d->br_rate, d->br_rate + nl);
+        cc.unavail.assign(d->unavail, d->unavail + ncomp); cc.always_up.assign(d->always_up, d->always_up + ncomp);
+        cc.d = *d;
+        cc.d.bus_pd = cc.bus_pd.data(); cc.d.inj_bus = cc.inj_bus.data(); cc.d.inj_pmin = cc.inj_pmin.data(); cc.d.inj_pmax = cc.inj_pmax.data(); cc.d.inj_cost = cc.inj_cost.data();
+        cc.d.br_from = cc.br_from.data(); cc.d.br_to = cc.br_to.data(); cc.d.br_b = cc.br_b.data(); cc.d.br_rate = cc.br_rate.data();
+        cc.d.unavail = cc.unavail.data(); cc.d.always_up = cc.always_up.data();
+        cc.valid = true;
+        ctx->alt_state[0] = ctx->alt_state[1] = 0; ctx->retry_units = 0; ctx->retry_converged = 0;
+    }
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
         ctx->tile = 0;
@@ -803,6 +996,14 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     }
     ctx->tile = 1;
     return case_load_impl<Tile96>(ctx, d, ctx->hcase96);
+}
+
+int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (units_out) *units_out = ctx->retry_units;
+    if (converged_out) *converged_out = ctx->retry_converged;
+    return RELMC_OK;
 }
 
 int32_t relmc_case_thresholds(const relmc_ctx* ctx, uint32_t* out)
@@ -862,9 +1063,26 @@ int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64
     EvalArgs a = make_args(o);
     a.n = n; a.states = states_dev; a.dns = dns_dev; a.nodal = nodal_dev; a.status = status_dev; a.iters = iters_dev;
     int blocks = 0;
-    int rc = launch_eval<1>(ctx, a, &blocks);
+    int rc = fail_arm(ctx, a, 0, true);
     if (rc) return rc;
-    return finish_timing(ctx);
+    rc = launch_eval<1>(ctx, a, &blocks);
+    if (rc) return rc;
+    rc = finish_timing(ctx);
+    if (rc) return rc;
+    RetryOut ro;
+    double ms = ctx->last_kernel_ms;
+    rc = fail_retry(ctx, o, a.fail_threshold, no_scale, false, ro, &ms);
+    if (rc) return rc;
+    ctx->last_kernel_ms = ms;
+    for (size_t r = 0; r < ro.rec.size(); ++r) {          // the second attempt's results in the place of the first's
+        const size_t u = (size_t)ro.rec[r].unit, nb = (size_t)ctx->nb;
+        const int32_t st = ro.meta[r] & 3, it = (int32_t)((uint32_t)ro.meta[r] >> 8);
+        HIP_TRY(ctx, hipMemcpy(dns_dev + u, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice));
+        if (nodal_dev) HIP_TRY(ctx, hipMemcpy(nodal_dev + u * nb, &ro.nodal[r * nb], sizeof(double) * nb, hipMemcpyHostToDevice));
+        if (status_dev) HIP_TRY(ctx, hipMemcpy(status_dev + u, &st, sizeof(int32_t), hipMemcpyHostToDevice));
+        if (iters_dev) HIP_TRY(ctx, hipMemcpy(iters_dev + u, &it, sizeof(int32_t), hipMemcpyHostToDevice));
+    }
+    return RELMC_OK;
 }
 
 int32_t relmc_mc_simulation(relmc_ctx* ctx, const uint8_t* states_host, int64_t n, const relmc_solver_opts* opts,
@@ -911,7 +1129,9 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
         a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
         a.dns = dns_dev ? dns_dev + done : nullptr;
         int blocks = 0;
-        int rc = launch_eval<0>(ctx, a, &blocks);
+        int rc = fail_arm(ctx, a, done, true);
+        if (rc) return rc;
+        rc = launch_eval<0>(ctx, a, &blocks);
         if (rc) return rc;
         rc = launch_finalize(ctx, blocks);
         if (rc) return rc;
@@ -920,6 +1140,13 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
         rc = finish_timing(ctx);
         if (rc) return rc;
         ms_total += ctx->last_kernel_ms;
+        RetryOut ro;
+        rc = fail_retry(ctx, o, a.fail_threshold, no_scale, false, ro, &ms_total);
+        if (rc) return rc;
+        for (size_t r = 0; r < ro.rec.size(); ++r) {
+            acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);
+            if (dns_dev) HIP_TRY(ctx, hipMemcpy(dns_dev + ro.rec[r].unit, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice));
+        }
         relmc_acc_merge(acc_out, &part);
         done += m;
     }
@@ -1022,6 +1249,8 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
         EvalArgs a = make_args(o);
         a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
         int rows = 0;
+        rc = fail_arm(ctx, a, 0, true);
+        if (rc) return rc;
         rc = launch_eval<3>(ctx, a, &rows);
         if (rc) return rc;
         rc = launch_finalize(ctx, rows);
@@ -1031,6 +1260,11 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
         rc = finish_timing(ctx);
         if (rc) return rc;
         ms_total += ctx->last_kernel_ms + prep_ms;       // sampling + sort + run-length encoding (host-timed) + evaluation kernel
+        RetryOut ro;
+        rc = fail_retry(ctx, o, a.fail_threshold, no_scale, false, ro, &ms_total);
+        if (rc) return rc;
+        for (size_t r = 0; r < ro.rec.size(); ++r)
+            acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);
         relmc_acc_merge(acc_out, &part);
         distinct_total += nu;
         done += m;
@@ -1233,11 +1467,22 @@ int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, 
             a.n = (int64_t)n_new; a.memo_keys = ctx->db_keys; a.db_first = ctx->db_n;
             a.dns = ctx->db_dns; a.status = ctx->db_meta; a.nodal = ctx->db_nodal;
             int rows = 0;
+            rc = fail_arm(ctx, a, 0, true);
+            if (rc) return rc;
             rc = launch_eval<4>(ctx, a, &rows);
             if (rc) return rc;
             rc = finish_timing(ctx);
             if (rc) return rc;
             eval_ms = ctx->last_kernel_ms;
+            RetryOut ro;
+            rc = fail_retry(ctx, o, a.fail_threshold, no_scale, false, ro, &eval_ms);
+            if (rc) return rc;
+            for (size_t r = 0; r < ro.rec.size(); ++r) {          // into the rows the first attempt filled
+                const size_t row = (size_t)ctx->db_n + (size_t)ro.rec[r].unit, nbz = (size_t)ctx->nb;
+                HIP_TRY(ctx, hipMemcpy(ctx->db_dns + row, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(ctx->db_meta + row, &ro.meta[r], sizeof(int32_t), hipMemcpyHostToDevice));
+                HIP_TRY(ctx, hipMemcpy(ctx->db_nodal + row * nbz, &ro.nodal[r * nbz], sizeof(double) * nbz, hipMemcpyHostToDevice));
+            }
             ctx->db_n += (int64_t)n_new;
         }
         ctx->db_samples += m;

@@ -100,6 +100,13 @@ struct PartialT {
     uint32_t pad;
 };
 
+// one unit the primary schedule did not converge on
+struct FailRec {
+    unsigned long long unit;        // launch-local index + unit_base: sample offset (MODE 0), state (1), distinct state (3), row offset (4)
+    uint32_t weight, pad;
+    uint32_t mask[8];               // outage mask words
+};
+
 struct EvalArgs {
     uint64_t seed, first_index;
     int64_t n;
@@ -134,6 +141,12 @@ struct EvalArgs {
     // MODE 4 (rows of the persistent state database): scenario u = row db_first + u, key words at memo_keys[row][OW],
     // results go to dns[row], status[row] (packed) and nodal[row][nb]
     int64_t db_first;
+    // Units (samples / states / rows) that end non-converged (status 1 or 2) are listed here instead of being accumulated; the host
+    // evaluates them again under the alternate elimination order (relmc_abi.hip: retry_failed).  Null = off (MODE 2 always).
+    uint32_t* fail_count;
+    FailRec* fail_list;
+    uint32_t fail_cap;
+    int64_t unit_base;              // added to the launch-local unit index (chunked host-buffer pipeline)
 };
 
 }  // namespace relmc

@@ -356,6 +356,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)a.memo_perm[s0] * OW + rlane];
             } else if (MODE == 4) {
                 if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)(a.db_first + sidx) * OW + rlane];
+                if (a.load_scale) lscale = a.load_scale[sidx];          // retry rows of the scaled-load entry point
             } else {
                 if (rlane < OW) OB[rlane] = 0u;
                 RELOAD_FENCE();
@@ -1056,6 +1057,23 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             double dns = fval + C.total_load * lscale;            // mc_simulation.m:54 / seq_mcsimulation.m:67
             if (dns < 0.1) dns = 0.0;
             const bool fail = dns > a.fail_threshold;             // nsqMain.m:270 (1e-4) / seqMain.m:41,140 (0.01)
+            // a unit the static pivot order did not converge on (6.7e-7 of the RTS-96 scenarios) goes to the retry list;
+            // it is accumulated here only if the list is off or full
+            bool defer = false;
+            if (MODE != 2 && a.fail_list && (status == 1 || status == 2)) {
+                uint32_t pos = 0;
+                if (rlane == 0) pos = atomicAdd(a.fail_count, 1u);
+                pos = __shfl(pos, lane & ~(RW - 1));
+                if (pos < a.fail_cap) {
+                    defer = true;
+                    FailRec* fr = a.fail_list + pos;
+                    if (rlane < OW) fr->mask[rlane] = OB[rlane];
+                    if (rlane == 0) {
+                        const int64_t u = (MODE == 0 && WINDOWED) ? wb * 4 + WINL[wg * 4 + lane / RW] : sidx;
+                        fr->unit = (unsigned long long)(u + a.unit_base); fr->weight = wgt; fr->pad = 0;
+                    }
+                }
+            }
             double shed[IS];
 #pragma unroll
             for (int s = 0; s < IS; ++s) {
@@ -1065,13 +1083,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     const double v = ip[s] * base - C.i_tab[j][3] * lscale;     // Pg - Pmin, mc_simulation.m:86
                     if (v > 1e-3) shed[s] = v;                           // mc_simulation.m:90
                 }
-                if (MODE != 4 && shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
-                if (MODE != 4 && fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += wgt;
+                if (MODE != 4 && !defer && shed[s] != 0.0) PA.shed[s] += MODE == 3 ? shed[s] * (double)wgt : shed[s];
+                if (MODE != 4 && !defer && fail && ((iinfo[s] >> 8) & 0xff) == IK_REAL && outbit(OB, j)) PA.cf_inj[s] += wgt;
             }
 #pragma unroll
             for (int s = 0; s < LS; ++s)
-                if (MODE != 4 && fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
-            if (MODE != 4 && rlane == 0) {          // row-uniform quantities: one lane per scenario row
+                if (MODE != 4 && !defer && fail && ((linfo[s] >> 24) & LF_EXISTS) && outbit(OB, ng + RW * s + rlane)) PA.cf_line[s] += wgt;
+            if (MODE != 4 && !defer && rlane == 0) {          // row-uniform quantities: one lane per scenario row
                 acc_n += wgt;
                 if (dns != 0.0) {
                     if (MODE == 3) { PA.dns = __builtin_fma((double)wgt, dns, PA.dns); PA.dns2 = __builtin_fma((double)wgt * dns, dns, PA.dns2); }

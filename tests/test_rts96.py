@@ -224,19 +224,23 @@ def test_oracle96_on_device_numfail_states(oracle96, numfail96):
 
 @pytest.mark.gpu
 def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
-    """The device on its own non-converged states against the oracle: the curtailment is the optimum on every one of them
-    (<= 1e-5 MW from the oracle, numpy MIPS and HiGHS); the STATUS differs where the oracle still converges (recorded: 62 of
-    67; on 5 the oracle fails as well) — counted here, documented in DESIGN.md 6.3.  The reference never reads the solver's
-    success flag (mc_simulation.m:41,54), so the indices are unaffected."""
+    """The 67 states (of 1e8 samples) on which the device's PRIMARY elimination order ends "numerically failed" (scanned in
+    round 2, fixture).  The curtailment is the optimum on every one of them (<= 1e-5 MW from the oracle, numpy MIPS and
+    HiGHS).  Every entry point now evaluates such a unit again under a second and, if need be, a third static order
+    (DESIGN.md 6.3): 66 converge under the second, the last one under the third; the C oracle converges on 62 of the 67."""
     from powersystemsreliabilityassessment_amd import api
     for name, pol in (("emulate", _abi.RELMC_REFERENCE_EMULATE), ("physical", _abi.RELMC_PHYSICAL)):
+        before = engine96.retry_stats()
         dns, nodal, info = engine96.mc_simulation(numfail96["matrix"], mpopt=api.mpoption(pol), return_info=True)
+        after = engine96.retry_stats()
+        assert after[0] - before[0] == 67 and after[1] - before[1] >= 66          # all 67 went to the further orders
         r = oracle96.mc_simulation(numfail96["matrix"], pol, nthreads=16)
         np.testing.assert_allclose(dns, r["dns"], rtol=0, atol=1e-5)
         assert set(np.unique(info["status"])) <= {0, 2}
-        dev_fail, orc_fail = info["status"] == 2, r["status"] == 2
-        assert dev_fail.sum() <= 67 and (dev_fail & ~orc_fail).sum() <= 62       # the recorded divergence, never more
-        assert np.all(info["iters"][dev_fail & ~orc_fail] >= r["iters"][dev_fail & ~orc_fail])
+        dev_ok, orc_ok = info["status"] == 0, r["status"] == 0
+        assert dev_ok.sum() >= 66 and (dev_ok & orc_ok).sum() >= 61
+        both = dev_ok & orc_ok
+        assert np.abs(info["iters"][both] - r["iters"][both]).max() <= 5 and (info["iters"][both] == r["iters"][both]).mean() > 0.75
         for i, x in enumerate(numfail96["states"]):
             e = x[name]
             assert dns[i] == pytest.approx(e["numpy_mips"]["dns"], abs=1e-5)
@@ -246,10 +250,41 @@ def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
 
 
 @pytest.mark.gpu
+def test_gpu96_retry_in_every_path(engine96, numfail96):
+    """The sample of the fixture's first state (index recorded by the scan) through the fused, the distinct-state, the database
+    and the per-state paths: each re-evaluates it, and the accumulators agree with one another."""
+    from powersystemsreliabilityassessment_amd import api
+    idx = int(numfail96["states"][0]["emulate"]["index"])
+    lo, n = idx - 1000, 2048
+    u0 = engine96.retry_stats()[0]
+    a = engine96.nsq_accumulate(1, lo, n)
+    u1 = engine96.retry_stats()[0]
+    d, _ = engine96.nsq_accumulate_distinct(1, lo, n)
+    u2 = engine96.retry_stats()[0]
+    engine96.db_reset()
+    b, _ = engine96.nsq_db_batch(1, lo, n)
+    u3 = engine96.retry_stats()[0]
+    st = engine96.mc_sampling(None, n, seed=1, first_index=lo)
+    dns, nodal, info = engine96.mc_simulation(st, return_info=True)
+    u4 = engine96.retry_stats()[0]
+    assert (u1 - u0, u2 - u1, u3 - u2, u4 - u3) == (1, 1, 1, 1)
+    assert a.n_nonconverged == d.n_nonconverged == b.n_nonconverged == int((info["status"] == 1).sum() + (info["status"] == 2).sum()) == 0
+    ai, ad = a.to_arrays()
+    for other in (d, b):
+        oi, od = other.to_arrays()
+        assert np.array_equal(ai, oi)
+        np.testing.assert_allclose(od, ad, rtol=1e-9, atol=1e-6)
+    assert ai[5] == info["iters"].sum() and abs(ad[0] - dns.sum()) < 1e-6
+    engine96.db_reset()
+
+
+@pytest.mark.gpu
 def test_gpu96_nonconverged_rate(engine96):
-    """4e6 scenarios: at most a handful end non-converged (measured 6.7e-7), none of them changes an index beyond 1e-9 relative."""
-    acc = engine96.nsq_accumulate(1, 0, 4_000_000)
-    assert acc.n_nonconverged <= 12
+    """2e7 scenarios: the primary order ends 6.7e-7 of them non-converged (13 expected here), the further orders none
+    (0 of the 67 in the first 1e8 samples, scripts/retry_soak.py)."""
+    u0 = engine96.retry_stats()[0]
+    acc = engine96.nsq_accumulate(1, 0, 20_000_000)
+    assert acc.n_nonconverged <= 1 and 3 <= engine96.retry_stats()[0] - u0 <= 40
 
 
 # ---- the sequential track on the wide tile (219 components: 8 mask words per hour) --------------------------------------
