@@ -240,7 +240,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
             // shallow elimination tree first (fewer dependent passes), then little fill
             long key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + b;
             if (order_variant == 1) key = ((long)lev * 1000 + fillc) * 10000 + deg * 100 + (nb - 1 - b);       // other tie-breaks
-            else if (order_variant == 2) key = ((long)fillc * 1000 + lev) * 10000 + deg * 100 + b;            // fill first;
+            else if (order_variant == 2) key = ((long)fillc * 1000 + lev) * 10000 + deg * 100 + b;            // fill first
 
             if (best < 0 || key < bestkey) { best = b; bestkey = key; }
         }
