@@ -153,6 +153,7 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_star
     // the grid fills the device: first-dispatched and later wavefronts share every SIMD (see the kernel's priority balancing)
     a.prio_mode = blocks != ctx->num_cu * ctx->blocks_per_cu ? 0u : (ctx->blocks_per_cu == 2 ? 1u : (ctx->blocks_per_cu == 1 && TL::WPB == 8 ? 2u : 0u));
     a.stash_off = alt ? ctx->alt_stash_off[alt - 1] : ctx->stash_off;
+    a.case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);
 #if defined(RELMC_PHASE_TIMING) || defined(RELMC_TRACE)
     if (!ctx->dtiming) HIP_TRY(ctx, hipMalloc(&ctx->dtiming, sizeof(unsigned long long) * 8 * 65536));
     a.timing = ctx->dtiming; ctx->timing_waves = blocks * TL::WPB;
@@ -589,7 +590,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
     const uint32_t stash_off = scen;
     scen += 2u * IS * ROWL + NBT + OW / 2u;                // stash: 1/D and Np/D per injection lane; lambda per bus; outage mask words
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
-    const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task) + ((uint32_t)C.npass + 1u) * (uint32_t)sizeof(C.task[0]);
+    const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);     // tables copied to LDS; the pass schedule is read from global memory
     const uint32_t lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");

@@ -123,6 +123,7 @@ struct EvalArgs {
     uint32_t prio_mode;             // issue-priority balancing between co-resident wavefronts: 0 off, 1 by grid half, 2 by wave half
     uint32_t scen_doubles;          // per-scenario LDS doubles (workspace + stash), = 2 mod 4
     uint32_t stash_off;             // start of the per-lane stash behind the workspace
+    uint32_t case_bytes;            // bytes of the case tables copied to LDS (everything before the pass schedule)
     unsigned long long* timing;     // profiling builds: [waves][8] phase cycle counters (else null)
     double fail_threshold;          // loss flag: dns > 1e-4 (nsqMain.m:270) / > 0.01 (seqMain.m:41)
     const double* load_scale;       // MODE 1: optional per-scenario load scale factor

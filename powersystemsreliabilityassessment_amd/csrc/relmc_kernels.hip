@@ -169,8 +169,16 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     double* const OPT = reinterpret_cast<double*>(smem);
 #define A_(k, name) OPT[k]
     DevCase& C = *reinterpret_cast<DevCase*>(smem + OPT_BYTES);
+    // Read-only tables that every iteration re-reads go through the vector-memory path (L1/L2 hits; its queue and `vmcnt` are otherwise
+    // idle in this kernel) where that was measured to pay, instead of through the LDS pipe, which is the kernel's tightest resource:
+    // the pass descriptors on both tiles (-2.0 % / -0.5 %), the injection table and the packed incidence lists on the wide tile (-1.9 %
+    // each; on the narrow tile they cost +1.5 %: four scenarios' worth of dependent work waits on each load).
+    const DevCase& TASKSRC = *gcase;
+    const DevCase& TABL = C;
+    const DevCase& TABI = (RW == 64) ? *gcase : C;
+    const DevCase& TABG = (RW == 64) ? *gcase : C;
     const int tid = threadIdx.x, lane = tid & 63, rlane = lane & (RW - 1), row = tid / RW;
-    const uint32_t case_bytes = (uint32_t)offsetof(DevCase, task) + ((uint32_t)gcase->npass + 1u) * (uint32_t)sizeof(C.task[0]);   // +1: descriptor prefetch
+    const uint32_t case_bytes = a.case_bytes;     // = offsetof(DevCase, task): the pass schedule behind it stays in global memory (read through L1)
     {
         const uint32_t* src = reinterpret_cast<const uint32_t*>(gcase);
         uint32_t* dst = reinterpret_cast<uint32_t*>(smem + OPT_BYTES);
@@ -201,8 +209,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     uint32_t linfo[LS]; int lpart[LS];
 #pragma unroll
     for (int s = 0; s < LS; ++s) { const int l = RW * s + rlane; linfo[s] = C.l_info[l]; lpart[s] = C.l_partner[l]; }
-#define lb(s) C.l_b[RW * (s) + rlane]
-#define lr(s) C.l_rate[RW * (s) + rlane]
+#define lb(s) TABL.l_b[RW * (s) + rlane]
+#define lr(s) TABL.l_rate[RW * (s) + rlane]
     uint32_t iinfo[IS];
 #pragma unroll
     for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[RW * s + rlane];
@@ -717,11 +725,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     mx_x = vmax(mx_x, __builtin_fabs(pv));
                     nanx = nanx || pv != pv;
                     if (I_BOX(s)) {
-                        const d2 hl = ld2(C.i_tab[j]);               // {upper, lower} bound
+                        const d2 hl = ld2(TABI.i_tab[j]);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
                         const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
                         const double D = imup[s] * rzp + imum[s] * rzm;
-                        const double lxp = C.i_tab[j][2] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
+                        const double lxp = TABI.i_tab[j][2] - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
                         invD = frcp(D); npd = np * invD;
                         mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
@@ -756,7 +764,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
                         // incidence lists come packed (one 8-byte LDS read each); unused slots point at the zero
                         // records, so all record loads of a bus are independent and issue back to back
-                        const unsigned long long pl = C.b_line8[bi], pj = C.b_inj8[bi];
+                        const unsigned long long pl = TABG.b_line8[bi], pj = TABG.b_inj8[bi];
                         // two list entries per step: their four (three) record loads issue together and one wait covers both;
                         // an odd list's last step reads the all-zero record once more (adds exact zeros)
 #pragma unroll
@@ -864,9 +872,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
                 // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
-                uint2 dsc = *reinterpret_cast<const uint2*>(&C.task[0][rlane][0]);
+                uint2 dsc = *reinterpret_cast<const uint2*>(&TASKSRC.task[0][rlane][0]);
                 for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
-                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         const bool vec = (dsc.x & 0x8000u) != 0;            // rhs pseudo-bus: Wa = [y_i'; 0], T = y_a'
                         double* T = W + (dsc.x & 0x7fffu);
@@ -894,7 +902,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
                 PT_MARK(4)
                 for (int p = npu; p < npu + npi; ++p) {      // D <- P = inv(D) in place; y <- P*y
-                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         double* D = W + (dsc.x & 0xffffu);
                         double* Y = W + (dsc.x >> 16);
@@ -909,7 +917,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
                 PT_MARK(5)
                 for (int p = npu + npi; p < npass; ++p) {    // y_i -= P_i * W' * x_a
-                    const uint2 nxt = *reinterpret_cast<const uint2*>(&C.task[p + 1][rlane][0]);
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         double* Yi = W + (dsc.x & 0xffffu);
                         const double* Wk = W + (dsc.x >> 16);
@@ -972,7 +980,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const double dlb = X[2 * (iinfo[s] & 0xff) + 1];
                             const d2 sh = ld2(Stash + 2 * RW * s);
                             dpv[s] = __builtin_fma(dlb, sh.x, -sh.y);   // dp = (-Np + dlam)/D
-                            const d2 hl = ld2(C.i_tab[j]);
+                            const d2 hl = ld2(TABI.i_tab[j]);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
@@ -1025,7 +1033,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     for (int s = 0; s < IS; ++s) {
                         if (I_BOX(s)) {
                             const int j = RW * s + rlane;
-                            const d2 hl = ld2(C.i_tab[j]);
+                            const d2 hl = ld2(TABI.i_tab[j]);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
@@ -1035,7 +1043,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
                             zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                         }
-                        fl = __builtin_fma(C.i_tab[RW * s + rlane][2], ip[s], fl);      // p = 0 on an injection out of service
+                        fl = __builtin_fma(TABI.i_tab[RW * s + rlane][2], ip[s], fl);      // p = 0 on an injection out of service
                         SLOT_FENCE();
                     }
 #pragma unroll

@@ -64,8 +64,8 @@ CASES = [
     (6, 32, 14, 28, 30, 0.5, 2, 0.0),      # the narrow tile's 32 buses, 48 lines
     (7, 16, 8, 12, 10, 0.5, 0, 0.3),       # generators with Pmin > 0
     (8, 40, 20, 45, 30, 0.45, 4, 0.0),     # first sizes of the wide tile
-    (9, 73, 18, 90, 51, 0.4, 6, 0.0),      # RTS-96-sized, another topology
-    (10, 100, 8, 120, 60, 0.5, 2, 0.0),    # 100 buses, 109 lines, 180 injections
+    (9, 73, 40, 90, 51, 0.4, 6, 0.0),      # RTS-96-sized, a denser topology (118 lines)
+    (10, 100, 20, 120, 60, 0.5, 2, 0.0),   # 100 buses, 121 lines, 180 injections
 ]
 
 
@@ -113,11 +113,10 @@ def test_random_case_matches_oracle(spec):
 
 def test_case_limits_are_reported():
     """Cases beyond what the compiled tiles hold are refused at relmc_case_load with a message, not mis-evaluated: more than
-    128 buses; a 73-bus network with 40 random chords (its fill needs more LDS per scenario than a workgroup of the wide tile
-    has); a triple circuit."""
+    128 buses or 126 lines; a triple circuit."""
     rng = np.random.default_rng(5)
     for case, text in ((random_case(rng, 140, 10, 60, 40), "exceeds the compiled tiles"),
-                       (random_case(np.random.default_rng(1010), 73, 40, 90, 51, 0.5, 2), "160 KiB of LDS")):
+                       (random_case(np.random.default_rng(1010), 100, 30, 120, 60, 0.5, 2), "exceeds the compiled tiles")):
         with pytest.raises(api.RelmcError) as e:
             api.Engine(case, device=0)
         assert "relmc_case_load" in str(e.value) and text in str(e.value)
