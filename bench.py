@@ -193,7 +193,8 @@ def main():
                                       f"({'RCCL through the C ABI' if comm is not None else 'torch.distributed ' + (args.backend if world > 1 else '(single rank: no collective)')})"},
             "roofline": roof,
             "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "plc": total.n_fail / n_total,
-                        "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged)},
+                        "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged),
+                        "second_attempts_rank0": list(eng.retry_stats())},     # units re-evaluated under a further elimination order, converged
         }
         if args.workload == "nsq24":
             idx = rdist.indices_from_acc(total, case.nb, case.ncomp)

@@ -64,7 +64,7 @@ struct relmc_ctx {
     static constexpr int kAlt = 2;           // further static orders: [0] the primary rule with the ties broken the other way, [1] fill first
     int alt_state[kAlt] = {0, 0};            // 0 not built yet, 1 ready, -1 unavailable (that order does not fit the tile)
     void* dcase_alt[kAlt] = {nullptr, nullptr}; uint32_t alt_scen_doubles[kAlt] = {0, 0}, alt_lds_bytes[kAlt] = {0, 0}, alt_stash_off[kAlt] = {0, 0};
-    FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr;
+    FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr; bool fail_dirty = false;
     uint32_t* rkeys = nullptr; double* rdns = nullptr; int32_t* rmeta = nullptr; double* rnodal = nullptr; double* rscale = nullptr; int64_t rcap = 0;
     int64_t retry_units = 0, retry_converged = 0;        // since the case was loaded
     unsigned long long* db_snap = nullptr; int64_t db_snap_cap = 0;      // row counts before a stretch of small batches (relmc_nsq_run)
@@ -659,9 +659,12 @@ int fail_arm(relmc_ctx* ctx, EvalArgs& a, int64_t unit_base, bool reset)
         HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * kFailCap));
         HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
         HIP_TRY(ctx, hipMemsetAsync(ctx->dfail, 0, sizeof(FailRec) * kFailCap, ctx->stream));
-        reset = true;
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
     }
-    if (reset) HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
+    // the count is zero whenever a call has collected its list (fail_retry zeroes it after a non-empty one), so the common case costs no
+    // memset launch; only a call that was abandoned between arming and collecting leaves it to be cleared here
+    if (reset && ctx->fail_dirty) { HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream)); }
+    if (reset) ctx->fail_dirty = true;
     a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap;
     return RELMC_OK;
 }
@@ -675,7 +678,9 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
     if (!ctx->dfail_count) return RELMC_OK;
     uint32_t cnt = 0;
     HIP_TRY(ctx, hipMemcpy(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost));
+    ctx->fail_dirty = false;
     if (cnt == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));
     if (cnt > kFailCap) cnt = kFailCap;                      // the units beyond the list were accumulated by the kernel as they were
     out.rec.resize(cnt);
     HIP_TRY(ctx, hipMemcpy(out.rec.data(), ctx->dfail, sizeof(FailRec) * cnt, hipMemcpyDeviceToHost));
