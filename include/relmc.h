@@ -298,8 +298,8 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
                         relmc_acc* acc_out);
 
 /* Units (samples, states, database rows) that the solver's static elimination order ends non-converged (status MAXIT or NUMFAIL;
- * 6.7e-7 of the RTS-96 scenarios, 4e-10 on RTS-24) are evaluated a second time under another static order by every entry point
- * except the sequential ones; the second attempt's results replace the first's.  Counters since relmc_case_load:
+ * 6.7e-7 of the RTS-96 scenarios, 4e-10 on RTS-24) are evaluated again under further static orders by every entry point, the
+ * sequential ones included; the later attempt's results replace the first's.  Counters since relmc_case_load:
  * units re-evaluated, and how many of them ended converged (or MATPOWER-singular).  RELMC_NO_RETRY=1 in the environment turns the
  * second attempt off (diagnosis). */
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);

@@ -173,10 +173,10 @@ class Oracle:
         return dict(dns=dns, nodal=nodal, status=status, iters=iters, relaxed=relaxed)
 
     def seq_years(self, rel, hours, load_factors, seed, first_year, n_years, policy=_abi.RELMC_REFERENCE_EMULATE,
-                  threshold=0.01, nthreads=None):
+                  threshold=0.01, nthreads=None, opts=None):
         mttf = np.ascontiguousarray(rel[:, 0], dtype=np.float64); mttr = np.ascontiguousarray(rel[:, 1], dtype=np.float64)
         lf = np.ascontiguousarray(load_factors, dtype=np.float64)
-        o = _abi.default_solver_opts(policy)
+        o = opts if opts is not None else _abi.default_solver_opts(policy)
         yrs = np.zeros((n_years, 4)); acc = _abi.Acc()
         rc = self.L.orc_seq_years(C.byref(self.h.desc), mttf.ctypes.data_as(_abi.c_double_p), mttr.ctypes.data_as(_abi.c_double_p), hours,
                                   lf.ctypes.data_as(_abi.c_double_p), seed, first_year, n_years, C.byref(o), threshold,

@@ -65,6 +65,7 @@ struct relmc_ctx {
     int alt_state[kAlt] = {0, 0};            // 0 not built yet, 1 ready, -1 unavailable (that order does not fit the tile)
     void* dcase_alt[kAlt] = {nullptr, nullptr}; uint32_t alt_scen_doubles[kAlt] = {0, 0}, alt_lds_bytes[kAlt] = {0, 0}, alt_stash_off[kAlt] = {0, 0};
     FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr; bool fail_dirty = false;
+    std::vector<double> hlf;                 // host copy of the hourly load factors (load scale of a re-evaluated hour)
     uint32_t* rkeys = nullptr; double* rdns = nullptr; int32_t* rmeta = nullptr; double* rnodal = nullptr; double* rscale = nullptr; int64_t rcap = 0;
     int64_t retry_units = 0, retry_converged = 0;        // since the case was loaded
     unsigned long long* db_snap = nullptr; int64_t db_snap_cap = 0;      // row counts before a stretch of small batches (relmc_nsq_run)
@@ -1605,6 +1606,7 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
     if (ctx->dlf) (void)hipFree(ctx->dlf);
     ctx->dlf = nullptr;
     HIP_TRY(ctx, hipMalloc(&ctx->dlf, sizeof(double) * hpy));
+    ctx->hlf.assign(load_factors, load_factors + hpy);
     HIP_TRY(ctx, hipMemcpy(ctx->dseq, &q, sizeof(q), hipMemcpyHostToDevice));
     HIP_TRY(ctx, hipMemcpy(ctx->dlf, load_factors, sizeof(double) * hpy, hipMemcpyHostToDevice));
     if (ctx->tile == 0) HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<2, Tile24>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
@@ -1699,12 +1701,21 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         a.n = nlp; a.seq_masks = dm; a.seq_offsets = doff; a.seq_hours = dhours; a.load_factors = ctx->dlf; a.curt = dcurt;
         a.seq_nyears = n_years; a.seq_hpy = hpy;
         int blocks = 0;
+        rc = fail_arm(ctx, a, 0, true);
+        if (rc) { cleanup(); return rc; }
         rc = launch_eval<2>(ctx, a, &blocks);
         if (rc) { cleanup(); return rc; }
         if (launch_finalize(ctx, blocks) != RELMC_OK || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
         rc = finish_timing(ctx);
         if (rc) { cleanup(); return rc; }
         ms = ctx->last_kernel_ms;
+        RetryOut ro;                                                   // hours the primary elimination order did not converge on
+        rc = fail_retry(ctx, o, curtail_threshold, [&](unsigned long long u) { return ctx->hlf[(size_t)(u % (unsigned long long)hpy)]; }, true, ro, &ms);
+        if (rc) { cleanup(); return rc; }
+        for (size_t r = 0; r < ro.rec.size(); ++r) {
+            acc_add_unit(acc_out, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, curtail_threshold);
+            if (hipMemcpy(dcurt + ro.rec[r].unit, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
+        }
     }
     hipLaunchKernelGGL(relmc_seq_annual_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dcurt, hpy, curtail_threshold, dyear);
     std::vector<double> yr((size_t)3 * n_years);

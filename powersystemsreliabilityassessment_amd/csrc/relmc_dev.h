@@ -102,7 +102,7 @@ struct PartialT {
 
 // one unit the primary schedule did not converge on
 struct FailRec {
-    unsigned long long unit;        // launch-local index + unit_base: sample offset (MODE 0), state (1), distinct state (3), row offset (4)
+    unsigned long long unit;        // launch-local index + unit_base: sample offset (MODE 0), state (1), year * hours + hour (2), distinct state (3), row offset (4)
     uint32_t weight, pad;
     uint32_t mask[8];               // outage mask words
 };
@@ -143,7 +143,7 @@ struct EvalArgs {
     // results go to dns[row], status[row] (packed) and nodal[row][nb]
     int64_t db_first;
     // Units (samples / states / rows) that end non-converged (status 1 or 2) are listed here instead of being accumulated; the host
-    // evaluates them again under the alternate elimination order (relmc_abi.hip: retry_failed).  Null = off (MODE 2 always).
+    // evaluates them again under further elimination orders (relmc_abi.hip: fail_retry).  Null = off.
     uint32_t* fail_count;
     FailRec* fail_list;
     uint32_t fail_cap;

@@ -1068,7 +1068,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             // a unit the static pivot order did not converge on (6.7e-7 of the RTS-96 scenarios) goes to the retry list;
             // it is accumulated here only if the list is off or full
             bool defer = false;
-            if (MODE != 2 && a.fail_list && (status == 1 || status == 2)) {
+            if (a.fail_list && (status == 1 || status == 2)) {
                 uint32_t pos = 0;
                 if (rlane == 0) pos = atomicAdd(a.fail_count, 1u);
                 pos = __shfl(pos, lane & ~(RW - 1));
@@ -1077,7 +1077,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     FailRec* fr = a.fail_list + pos;
                     if (rlane < OW) fr->mask[rlane] = OB[rlane];
                     if (rlane == 0) {
-                        const int64_t u = (MODE == 0 && WINDOWED) ? wb * 4 + WINL[wg * 4 + lane / RW] : sidx;
+                        const int64_t u = (MODE == 0 && WINDOWED) ? wb * 4 + WINL[wg * 4 + lane / RW]
+                                          : (MODE == 2 ? (int64_t)seq_year * a.seq_hpy + seq_hour : sidx);      // MODE 2: the hour of the chronology
                         fr->unit = (unsigned long long)(u + a.unit_base); fr->weight = wgt; fr->pad = 0;
                     }
                 }
