@@ -303,6 +303,11 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
  * units re-evaluated, and how many of them ended converged (or MATPOWER-singular).  RELMC_NO_RETRY=1 in the environment turns the
  * second attempt off (diagnosis). */
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);
+/* relmc_case_load evaluates 8192 sampled states under the primary static order; a case on which more than 0.1 % of them end
+ * non-converged gets the further orders probed on the same sample and the best of the three as its primary.  primary_out: 0 = the
+ * default (level-then-fill), 1 = the same with the ties broken the other way, 2 = fill first; probe_failures_out: failures of each
+ * probed order among the 8192 (-1 = not probed).  RTS-24 and RTS-96: {0, -1, -1}, nothing changes. */
+int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t probe_failures_out[3]);
 
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
 /* Batches of up to 131072 samples (the reference's is 100, nsqMain.m:60) are evaluated many at a time in the modes

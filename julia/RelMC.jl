@@ -172,6 +172,12 @@ function retry_stats(eng::Engine)
     check(ccall((:relmc_retry_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), eng.h, u, c), eng.h, "relmc_retry_stats")
     return (u[], c[])
 end
+"(primary static elimination order 0/1/2, failures of each probed order among the 8192 calibration states; -1 = not probed)"
+function case_order(eng::Engine)
+    p = Ref{Int32}(0); f = zeros(Int32, 3)
+    check(ccall((:relmc_case_order, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ptr{Int32}), eng.h, p, f), eng.h, "relmc_case_order")
+    return (Int(p[]), f)
+end
 "(rows, samples) of the state database"
 function db_size(eng::Engine)
     rows = Ref{Int64}(0); samples = Ref{Int64}(0)

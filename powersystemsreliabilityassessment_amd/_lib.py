@@ -25,7 +25,7 @@ EXPORTS = [
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
     "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy",
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export",
-    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats",
+    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_case_order",
 ]
 
 
@@ -121,6 +121,8 @@ def load():
     L.relmc_db_size.restype = C.c_int32
     L.relmc_retry_stats.argtypes = [vp, _abi.c_int64_p, _abi.c_int64_p]
     L.relmc_retry_stats.restype = C.c_int32
+    L.relmc_case_order.argtypes = [vp, i32p, i32p]
+    L.relmc_case_order.restype = C.c_int32
     L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p]
     L.relmc_db_export.restype = C.c_int32
     if hasattr(L, "relmc_dpp_probe"):

@@ -280,6 +280,13 @@ class Engine:
         self._check(self.L.relmc_retry_stats(self._h, C.byref(u), C.byref(c)), "relmc_retry_stats")
         return int(u.value), int(c.value)
 
+    def case_order(self):
+        """(primary static elimination order 0/1/2, failures of each probed order among the 8192 calibration states; -1 = not
+        probed) — relmc_case_order."""
+        p = C.c_int32(); f = (C.c_int32 * 3)()
+        self._check(self.L.relmc_case_order(self._h, C.byref(p), f), "relmc_case_order")
+        return int(p.value), [int(x) for x in f]
+
     def db_export(self, first_row: int = 0, n_rows: int | None = None) -> dict:
         """Rows of the database in the reference's column layout (nsqMain.m:91-99): states, count, dns, flag, nodal
         (+ solver status and iteration count)."""

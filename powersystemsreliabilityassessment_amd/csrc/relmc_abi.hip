@@ -68,6 +68,7 @@ struct relmc_ctx {
     std::vector<double> hlf;                 // host copy of the hourly load factors (load scale of a re-evaluated hour)
     uint32_t* rkeys = nullptr; double* rdns = nullptr; int32_t* rmeta = nullptr; double* rnodal = nullptr; double* rscale = nullptr; int64_t rcap = 0;
     int64_t retry_units = 0, retry_converged = 0;        // since the case was loaded
+    int order_primary = 0; int32_t order_probe[3] = {-1, -1, -1};   // which static order runs first, and the calibration's failure counts (-1 = not probed)
     unsigned long long* db_snap = nullptr; int64_t db_snap_cap = 0;      // row counts before a stretch of small batches (relmc_nsq_run)
     // host-buffer entry points (relmc_mc_simulation, relmc_seq_mcsimulation): double-buffered chunk pipeline, device buffers
     // and pinned staging kept across calls
@@ -602,6 +603,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
         uint32_t most = ctx->lds_bytes;
         for (int q = 0; q < relmc_ctx::kAlt; ++q) if (ctx->alt_lds_bytes[q] > most) most = ctx->alt_lds_bytes[q];
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase_alt[v], &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return RELMC_OK;
@@ -766,6 +768,72 @@ void acc_add_unit(relmc_acc* acc, const FailRec& rec, double dns, int32_t meta, 
     if (dns != 0.0) { acc->sum_dns += (double)w * dns; acc->sum_dns2 += (double)w * dns * dns; }
     if (fail) for (int k = 0; k < ncomp; ++k) if ((rec.mask[k >> 5] >> (k & 31)) & 1u) acc->comp_fail[k] += w;
     for (int i = 0; i < nb; ++i) acc->sum_nodal[i] += (double)w * nodal[i];
+}
+
+// Which static order should run first?  relmc_case_load evaluates a fixed sample of states under the primary order and counts the
+// non-converged ones.  None (RTS-24, RTS-96: the rates are 4e-10 and 6.7e-7) keeps everything as it is; a case on which the primary order
+// fails often (a 7-bus network of the fuzz run: 6 % of its states) gets the two further orders built and probed on the same sample, and
+// the one with the fewest failures becomes the primary, the others the retry levels.
+constexpr int64_t kProbeSamples = 8192;
+int order_probe(relmc_ctx* ctx, int alt, int32_t* failures)
+{
+    relmc_solver_opts o; relmc_solver_opts_default(&o);
+    EvalArgs a = make_args(o);
+    a.seed = 0x5eedca5eull; a.first_index = 0; a.n = kProbeSamples;
+    if (!ctx->dfail) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * kFailCap));
+        HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail, 0, sizeof(FailRec) * kFailCap, ctx->stream));
+    }
+    HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
+    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap; a.unit_base = 0;
+    int rows = 0;
+    int rc = launch_eval<0>(ctx, a, &rows, nullptr, nullptr, alt);
+    if (rc) return rc;
+    uint32_t cnt = 0;
+    HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));
+    ctx->fail_dirty = false;
+    *failures = (int32_t)cnt;
+    return RELMC_OK;
+}
+
+int order_calibrate(relmc_ctx* ctx)
+{
+    ctx->order_primary = 0; ctx->order_probe[0] = ctx->order_probe[1] = ctx->order_probe[2] = -1;
+    if (getenv("RELMC_NO_RETRY")) return RELMC_OK;
+    int rc = order_probe(ctx, 0, &ctx->order_probe[0]);
+    if (rc) return rc;
+    if ((int64_t)ctx->order_probe[0] * 1000 <= kProbeSamples) return RELMC_OK;          // at most 0.1 %: the retry levels deal with those
+    int best = 0;
+    for (int v = 0; v < relmc_ctx::kAlt; ++v) {
+        if (alt_ensure(ctx, v) != RELMC_OK) continue;
+        rc = order_probe(ctx, v + 1, &ctx->order_probe[v + 1]);
+        if (rc) return rc;
+        if (ctx->order_probe[v + 1] < ctx->order_probe[best]) best = v + 1;
+    }
+    if (best != 0 && ctx->order_probe[best] * 2 <= ctx->order_probe[0]) {
+        const int v = best - 1;                        // that image becomes the primary, the former primary takes its retry level
+        std::swap(ctx->dcase, ctx->dcase_alt[v]);
+        std::swap(ctx->scen_doubles, ctx->alt_scen_doubles[v]); std::swap(ctx->lds_bytes, ctx->alt_lds_bytes[v]); std::swap(ctx->stash_off, ctx->alt_stash_off[v]);
+        ctx->order_primary = best;
+        int bpc = 0; hipError_t e = hipSuccess;
+        const int lds = (int)ctx->lds_bytes;
+        if (ctx->tile == 0) {
+            for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile24>),
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile24>)})
+                if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile24>, 64 * Tile24::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
+        } else {
+            for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile96>),
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile96>)})
+                if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
+            if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile96>, 64 * Tile96::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
+        }
+        HIP_TRY(ctx, e);
+    }
+    return RELMC_OK;
 }
 
 // ---- host-buffer evaluation: states in pageable host memory -> dns / nodal / status / iterations in host memory ---------
@@ -999,10 +1067,21 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
         ctx->tile = 0;
-        return case_load_impl<Tile24>(ctx, d, ctx->hcase24);
+        const int rc = case_load_impl<Tile24>(ctx, d, ctx->hcase24);
+        return rc ? rc : order_calibrate(ctx);
     }
     ctx->tile = 1;
-    return case_load_impl<Tile96>(ctx, d, ctx->hcase96);
+    const int rc = case_load_impl<Tile96>(ctx, d, ctx->hcase96);
+    return rc ? rc : order_calibrate(ctx);
+}
+
+int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t probe_failures_out[3])
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return RELMC_ERR_NO_CASE;
+    if (primary_out) *primary_out = ctx->order_primary;
+    if (probe_failures_out) for (int k = 0; k < 3; ++k) probe_failures_out[k] = ctx->order_probe[k];
+    return RELMC_OK;
 }
 
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out)

@@ -38,6 +38,6 @@ for k in range(n_cases):
         for i in np.flatnonzero(bad)[:3]:
             line += " [state %d: device %d/%d it, oracle %d/%d it, dns %.6f vs %.6f]" % (i, info["status"][i], info["iters"][i], ref["status"][i], ref["iters"][i], dns[i], ref["dns"][i])
     tot["retried"] += eng.retry_stats()[0]
-    print(line + " second attempts %s" % (eng.retry_stats(),), flush=True)
+    print(line + " second attempts %s order %s" % (eng.retry_stats(), eng.case_order()), flush=True)
     eng.close()
 print("total", tot)
