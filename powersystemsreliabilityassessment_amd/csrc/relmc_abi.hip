@@ -495,6 +495,43 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                     if (tasks[ti].kind == 1) { C.task[p][r][2] = 0; C.task[p][r][3] = 0; }
                 }
         }
+        // the sparsely filled PK_UPD passes at the end of the phase in quarter form (relmc_dev.h)
+        {
+            int nup = 0;
+            for (size_t q = 0; q < pkind.size(); ++q) if (pkind[q] == 0) nup++;
+            int nq = 0;
+            while (nq < nup && pcount[nup - 1 - nq] <= ROWL / 4 && !getenv("RELMC_NO_QUARTER")) nq++;
+            C.npass_updq = (uint16_t)nq;
+            int nh = 0;
+            while (nq + nh < nup && pcount[nup - 1 - nq - nh] <= ROWL / 2 && !getenv("RELMC_NO_HALF") && !getenv("RELMC_NO_QUARTER")) nh++;
+            C.npass_updh = (uint16_t)nh;
+            for (int p = nup - nq - nh; p < nup - nq; ++p) {
+                uint16_t full[ROWL][4]; int nfull = 0;
+                for (int r = 0; r < ROWL; ++r) if (C.task[p][r][0] != 0xffff) { for (int k = 0; k < 4; ++k) full[nfull][k] = C.task[p][r][k]; nfull++; }
+                for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[p][r][k] = 0xffff;
+                for (int t = 0; t < nfull; ++t) {
+                    const bool vec = (full[t][0] & 0x8000u) != 0;
+                    const int T = full[t][0] & 0x7fff, Wa = full[t][1], Wb = full[t][2], D = full[t][3];
+                    for (int r = 0; r < (vec ? 1 : 2); ++r) {
+                        uint16_t* q = C.task[p][2 * t + r];
+                        q[0] = (uint16_t)(T + 2 * r); q[1] = (uint16_t)(Wa + 2 * r); q[2] = (uint16_t)Wb; q[3] = (uint16_t)D;
+                    }
+                }
+            }
+            for (int p = nup - nq; p < nup; ++p) {
+                uint16_t full[ROWL][4]; int nfull = 0;
+                for (int r = 0; r < ROWL; ++r) if (C.task[p][r][0] != 0xffff) { for (int k = 0; k < 4; ++k) full[nfull][k] = C.task[p][r][k]; nfull++; }
+                for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[p][r][k] = 0xffff;
+                for (int t = 0; t < nfull; ++t) {
+                    const bool vec = (full[t][0] & 0x8000u) != 0;
+                    const int T = full[t][0] & 0x7fff, Wa = full[t][1], Wb = full[t][2], D = full[t][3];
+                    for (int r = 0; r < (vec ? 1 : 2); ++r) for (int c = 0; c < 2; ++c) {
+                        uint16_t* q = C.task[p][4 * t + 2 * r + c];
+                        q[0] = (uint16_t)(T + 2 * r + c); q[1] = (uint16_t)(Wa + 2 * r); q[2] = (uint16_t)(Wb + 2 * c); q[3] = (uint16_t)D;
+                    }
+                }
+            }
+        }
         C.npass = (uint16_t)pkind.size();
         int nu = 0, ni = 0;
         for (size_t q = 0; q < pkind.size(); ++q) {

@@ -40,6 +40,11 @@ constexpr uint32_t LF_EXISTS = 1u, LF_OWNER = 2u, LF_LIMITED = 4u;
 constexpr uint32_t IK_NONE = 0u, IK_REAL = 1u, IK_VIRTUAL = 2u;
 
 // Static solver schedule.  Passes [0, npass_upd) are PK_UPD, then npass_inv PK_INV, then PK_BWD.
+// The last npass_updq PK_UPD passes hold at most RW / 4 tasks each (the top of the elimination tree) and come in QUARTER form: four lanes
+// per task, lane 2r + c updating the single element T[r][c] -= (Wa[r] * inv(D)) . Wb[c] -- the same arithmetic per element, six LDS
+// instructions per pass instead of ten, which is what a pass costs whatever its fill.  Quarter descriptor = (&T[r][c], &Wa[r][0], &Wb[c][0], D).
+// In front of them, npass_updh passes of at most RW / 2 tasks in HALF form: two lanes per task, lane r updating the row T[r][:] (seven LDS
+// instructions).  Half descriptor = (&T[r][0], &Wa[r][0], Wb, D).
 //   PK_UPD  T -= Wa * inv(D) * Wb'         task = (T, Wa, Wb, D)      W offsets of 2x2 blocks
 //   PK_INV  P = inv(D); y <- P * y         task = (D, Y, P, -)
 //   PK_BWD  y_i -= P_i * W' * x_a          task = (Y_i, W, P_i, Y_a)
@@ -58,8 +63,9 @@ struct DevCaseT {
     uint32_t nws;                   // doubles in W
     uint16_t off_rhs, off_p;
     uint16_t npass, npass_upd, npass_inv, nzero;
-    uint16_t maxdeg, maxinj, base_connected, pad2;   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
+    uint16_t maxdeg, maxinj, base_connected, npass_updq;   // npass_updq: the last PK_UPD passes in quarter form (below)   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
     uint16_t maxdeg_s[2], maxinj_s[2];   // longest line / injection list among the buses of bus slot 0 / 1
+    uint16_t npass_updh, pad3[3];   // PK_UPD passes in half form, in front of the quarter-form ones
     uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), unused entries = nl (the all-zero record)
     uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, unused entries = ninj (the all-zero record)
     // lines

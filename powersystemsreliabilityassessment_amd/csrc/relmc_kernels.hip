@@ -201,7 +201,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
-    const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero;
+    const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero, npuh = C.npass_upd - C.npass_updq, npuf = npuh - C.npass_updh;
     const double base = C.base_mva;
     const double eps = 2.220446049250313e-16;
 
@@ -885,7 +885,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
                 // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
                 uint2 dsc = *reinterpret_cast<const uint2*>(&TASKSRC.task[0][rlane][0]);
-                for (int p = 0; p < npu; ++p) {              // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
+                for (int p = 0; p < npuf; ++p) {             // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         const bool vec = (dsc.x & 0x8000u) != 0;            // rhs pseudo-bus: Wa = [y_i'; 0], T = y_a'
@@ -909,6 +909,44 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
                             st2(T + 2, t1.x, t1.y);
                         }
+                    }
+                    dsc = nxt;
+                }
+                for (int p = npuf; p < npuh; ++p) {          // the same update, one row of T per lane (passes filled to at most a half, relmc_dev.h)
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
+                    if ((dsc.x & 0xffffu) != 0xffffu) {
+                        double* T = W + (dsc.x & 0xffffu);
+                        const double* Wa = W + (dsc.x >> 16);
+                        const double* Wb = W + (dsc.y & 0xffffu);
+                        const double* D = W + (dsc.y >> 16);
+                        const d2 dA = ld2(D); const double dBy = D[3];
+                        const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
+                        d2 t0 = ld2(T);
+                        const double pm = dA.x, pb = dA.y, pe = -dBy;
+                        const double q = frcp(__builtin_fma(pm, pe, pb * pb));
+                        const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
+                        const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
+                        t0.x -= __builtin_fma(g00, b0.x, g01 * b0.y); t0.y -= __builtin_fma(g00, b1.x, g01 * b1.y);
+                        st2(T, t0.x, t0.y);
+                    }
+                    dsc = nxt;
+                }
+                for (int p = npuh; p < npu; ++p) {           // the same update, one element of T per lane (sparsely filled passes, relmc_dev.h)
+                    const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
+                    if ((dsc.x & 0xffffu) != 0xffffu) {
+                        double* T = W + (dsc.x & 0xffffu);
+                        const double* Wa = W + (dsc.x >> 16);
+                        const double* Wb = W + (dsc.y & 0xffffu);
+                        const double* D = W + (dsc.y >> 16);
+                        const d2 dA = ld2(D); const double dBy = D[3];
+                        const d2 a0 = ld2(Wa), b0 = ld2(Wb);
+                        double t = *T;
+                        const double pm = dA.x, pb = dA.y, pe = -dBy;
+                        const double q = frcp(__builtin_fma(pm, pe, pb * pb));
+                        const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
+                        const double g0 = __builtin_fma(a0.x, P00, a0.y * P01), g1 = __builtin_fma(a0.x, P01, a0.y * P11);
+                        t -= __builtin_fma(g0, b0.x, g1 * b0.y);
+                        *T = t;
                     }
                     dsc = nxt;
                 }
