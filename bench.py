@@ -264,10 +264,12 @@ def counters_from_profile(workload, units_per_launch, n_cu):
             summ = json.load(fh)
     except (OSError, ValueError):
         return none
-    ev = [k for k in summ if "eval_kernel" in k]
+    # the workload's production kernel = the eval-kernel entry that did the work (MODE 5, the one short order-calibration launch of
+    # relmc_case_load, and MODE 4, the rows re-evaluated under a further elimination order, are eval kernels too)
+    ev = [k for k in summ if "eval_kernel" in k and "pmc_sq" in summ[k] and "pmc_lds" in summ[k]]
     if not ev:
         return none
-    k = summ[ev[0]]
+    k = summ[max(ev, key=lambda q: summ[q]["pmc_sq"]["sums"].get("SQ_INSTS_VALU", 0.0))]
     try:
         sq, lds = k["pmc_sq"]["sums"], k["pmc_lds"]["sums"]
         n_disp = max(1, k["pmc_lds"]["dispatches"])

@@ -641,12 +641,14 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
         for (int q = 0; q < relmc_ctx::kAlt; ++q) if (ctx->alt_lds_bytes[q] > most) most = ctx->alt_lds_bytes[q];
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
         HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
+        HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<5, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)most));
         HIP_TRY(ctx, hipMemcpyAsync(ctx->dcase_alt[v], &C, sizeof(C), hipMemcpyHostToDevice, ctx->stream));
         HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         return RELMC_OK;
     }
     ctx->stash_off = stash_off; ctx->scen_doubles = scen; ctx->lds_bytes = lds_bytes;
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<5, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
@@ -825,7 +827,7 @@ int order_probe(relmc_ctx* ctx, int alt, int32_t* failures)
     HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
     a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap; a.unit_base = 0;
     int rows = 0;
-    int rc = launch_eval<0>(ctx, a, &rows, nullptr, nullptr, alt);
+    int rc = launch_eval<5>(ctx, a, &rows, nullptr, nullptr, alt);      // MODE 5 = MODE 0 under its own kernel name
     if (rc) return rc;
     uint32_t cnt = 0;
     HIP_TRY(ctx, hipMemcpyAsync(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost, ctx->stream));
@@ -859,12 +861,14 @@ int order_calibrate(relmc_ctx* ctx)
         const int lds = (int)ctx->lds_bytes;
         if (ctx->tile == 0) {
             for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile24>),
-                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile24>)})
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile24>),
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile24>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile24>, 64 * Tile24::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
         } else {
             for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile96>),
-                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile96>)})
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile96>),
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile96>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile96>, 64 * Tile96::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
         }

@@ -45,8 +45,9 @@ for lg in ("trace_bench.log", "pmc_sq.log"):
         ttc = line.get("time_to_cov_1pct", {}).get("samples", 0)
         scen = n_pmc + ttc
         summary["units_per_profiled_launch"] = scen
-        ev = [k for k in summary if "eval_kernel" in k]
-        if ev and "pmc_fetch" in summary[ev[0]] and "pmc_write" in summary[ev[0]]:
+        ev = [k for k in summary if "eval_kernel" in k and "pmc_fetch" in summary[k] and "pmc_write" in summary[k] and "pmc_sq" in summary[k]]
+        ev.sort(key=lambda k: -summary[k]["pmc_sq"]["sums"].get("SQ_INSTS_VALU", 0.0))      # the production kernel, not the calibration probe
+        if ev:
             fk = summary[ev[0]]["pmc_fetch"]["sums"]["FETCH_SIZE"]; wk = summary[ev[0]]["pmc_write"]["sums"]["WRITE_SIZE"]
             b = (2.0 * fk + wk) * 1024.0
             summary["hbm_traffic"] = {
