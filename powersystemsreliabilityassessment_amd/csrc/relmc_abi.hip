@@ -353,6 +353,60 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                     const int j = succ[i][k];
                     if (tasks[j].kind == tasks[i].kind && depth[j] + succw[i][k] > depth[i]) depth[i] = depth[j] + succw[i][k];
                 }
+            // A pass costs its LDS instructions whatever its fill, and an update pass filled to at most a half / a quarter runs in the
+            // cheaper half / quarter form (relmc_dev.h): 10 / 7 / 6 instructions.  So the update phase is scheduled twice or more: with
+            // the full row width throughout, and with only half of it from pass F on; the cheapest variant that needs no extra pass wins.
+            auto upd_cost = [&](size_t first_pass) {
+                long c = 0;
+                for (size_t q = first_pass; q < pcount.size(); ++q) c += pcount[q] > ROWL / 2 ? 10 : (pcount[q] > ROWL / 4 ? 7 : 6);
+                return c;
+            };
+            int best_f = 1 << 30;                                       // pass index from which the narrow capacity applies (none)
+            {
+                long best_cost = -1; size_t best_n = 0;
+                for (int trial = -1; trial < MAXPASS; ++trial) {
+                    const int f_try = trial < 0 ? (1 << 30) : trial;
+                    std::vector<int> remaining;
+                    for (int i = 0; i < nt; ++i) if (tasks[i].kind == 0) remaining.push_back(i);
+                    std::vector<int> po(passof);
+                    std::vector<int> cnt;
+                    bool fits = true;
+                    while (!remaining.empty()) {
+                        const int cur = (int)cnt.size();
+                        if (cur >= MAXPASS - 1) { fits = false; break; }
+                        const int cap = cur >= f_try ? ROWL / 2 : ROWL;
+                        std::vector<int> ready;
+                        for (int i : remaining) {
+                            bool ok = true;
+                            for (int q : strict[i]) if (po[q] < 0 || po[q] >= cur) { ok = false; break; }
+                            if (ok) ready.push_back(i);
+                        }
+                        std::stable_sort(ready.begin(), ready.end(), [&](int a2, int b2) { return depth[a2] != depth[b2] ? depth[a2] > depth[b2] : a2 < b2; });
+                        std::vector<char> in_pass(nt, 0); int n_in = 0;
+                        std::vector<int> chosen;
+                        for (int i : ready) {
+                            if (n_in >= cap) break;
+                            bool ok = true;
+                            for (int q : weak[i]) if (po[q] < 0 && !in_pass[q]) { ok = false; break; }
+                            if (ok) { chosen.push_back(i); in_pass[i] = 1; n_in++; }
+                        }
+                        if (chosen.empty()) { fits = false; break; }
+                        for (int i : chosen) po[i] = cur;
+                        cnt.push_back(n_in);
+                        std::vector<int> rest;
+                        for (int i : remaining) if (po[i] < 0) rest.push_back(i);
+                        remaining.swap(rest);
+                    }
+                    if (!fits) { if (trial < 0) break; else continue; }
+                    pcount = cnt;
+                    const long c = upd_cost(0);
+                    pcount.clear();
+                    if (trial < 0) { best_cost = c; best_n = cnt.size(); best_f = f_try; }
+                    else if (cnt.size() <= best_n && c < best_cost) { best_cost = c; best_f = f_try; }
+                    if (trial >= 0 && (size_t)trial >= best_n) break;
+                }
+                if (getenv("RELMC_NO_QUARTER")) best_f = 1 << 30;
+            }
             for (int kind = 0; kind < 3; ++kind) {
                 std::vector<int> remaining;
                 for (int i = 0; i < nt; ++i) if (tasks[i].kind == kind) remaining.push_back(i);
@@ -368,8 +422,9 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                     std::stable_sort(ready.begin(), ready.end(), [&](int a2, int b2) { return depth[a2] != depth[b2] ? depth[a2] > depth[b2] : a2 < b2; });
                     std::vector<int> chosen;
                     std::vector<char> in_pass(nt, 0);
+                    const int cap = (kind == 0 && cur >= best_f) ? ROWL / 2 : ROWL;
                     for (int i : ready) {
-                        if ((int)chosen.size() >= ROWL) break;
+                        if ((int)chosen.size() >= cap) break;
                         bool ok = true;                                   // readers of what this task overwrites: already placed, or in this pass
                         for (int q : weak[i]) if (passof[q] < 0 && !in_pass[q]) { ok = false; break; }
                         if (ok) { chosen.push_back(i); in_pass[i] = 1; }
