@@ -319,6 +319,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
         const int nunits = (int)C.nws / 2 + 2;
         std::vector<int> lastw(nunits, -1), lastr(nunits, -1), pkind, pcount;
         std::vector<std::vector<int>> pass_tasks;          // pass -> RW slots, task index or -1
+        const auto t_sched0 = std::chrono::steady_clock::now();
         for (int q = 0; q < MAXPASS; ++q) for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[q][r][k] = 0xffff;   // null task
         // List scheduling by longest remaining dependency path (round 2; the round-1 scheduler placed the tasks as soon as
         // possible in generation order and needed one more update pass on both test systems).  Dependencies in the sequential
@@ -439,6 +440,8 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
             }
         }
         (void)lastw; (void)lastr;
+        const auto t_place0 = std::chrono::steady_clock::now();
+        if (getenv("RELMC_VERBOSE")) fprintf(stderr, "relmc: scheduling %.1f ms\n", std::chrono::duration<double, std::milli>(t_place0 - t_sched0).count());
         // ---- LDS bank-conflict aware placement (host only; the passes and their dependencies are untouched).
         // ds_read_b128 serves a wavefront in four fixed 16-lane groups (MI355X_MICROARCH.md), bank = (byte address / 4) mod 64:
         // a group is conflict-free when its 16 lanes hit 16 different 16-byte bank slots.  Two degrees of freedom cost
@@ -520,7 +523,9 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                     }
                 }
             std::vector<int> touched; std::vector<long> newc;
-            const int moves = noff > 0 ? 400 * (nb + noff) : 0;
+            // 100 moves per block: 36 / 114 ms of relmc_case_load on RTS-24 / RTS-96; 400 (round 1) took 144 / 440 ms for kernel times within
+            // run-to-run noise of these (19.0 vs 19.2 ms, 78.4 vs 78.2 ms per 1e6); no search at all: 19.2 / 79.3 ms
+            const int moves = noff > 0 ? (getenv("RELMC_PLACE_MOVES") ? atoi(getenv("RELMC_PLACE_MOVES")) : 100) * (nb + noff) : 0;
             for (int it = 0; it < moves && total > 0; ++it) {
                 if (rnd(10) < 6) {                                  // swap the positions of two off-diagonal blocks
                     const int i = nb + rnd(noff), j = nb + rnd(noff);
@@ -542,6 +547,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                 }
             }
             ctx->conflict_before = before; ctx->conflict_after = total;
+            if (getenv("RELMC_VERBOSE")) fprintf(stderr, "relmc: placement search %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_place0).count());
             for (int p = 0; p < np; ++p)
                 for (int r = 0; r < ROWL; ++r) {
                     const int ti = pass_tasks[p][r];
