@@ -2232,6 +2232,7 @@ int32_t relmc_debug_schedule(const relmc_ctx* ctx, int32_t* out9)
         out9[0] = C.npass_upd; out9[1] = C.npass_inv; out9[2] = C.npass - C.npass_upd - C.npass_inv; out9[3] = C.noff;
         out9[4] = C.nzero; out9[5] = (int)C.nws; out9[6] = (int)ctx->lds_bytes; out9[7] = ctx->blocks_per_cu; out9[8] = ntask;
         if (getenv("RELMC_VERBOSE")) fprintf(stderr, "relmc: modelled LDS conflict cycles per Newton step %ld -> %ld\n", ctx->conflict_before, ctx->conflict_after);
+        if (getenv("RELMC_VERBOSE")) fprintf(stderr, "relmc: longest line / injection list per bus slot: %d %d / %d %d\n", (int)C.maxdeg_s[0], (int)C.maxdeg_s[1], (int)C.maxinj_s[0], (int)C.maxinj_s[1]);
         if (getenv("RELMC_VERBOSE")) { fprintf(stderr, "relmc: tasks per pass:"); for (int p = 0; p < C.npass; ++p) fprintf(stderr, " %d", (int)C.pass_ntask[p]); fprintf(stderr, "\n"); }
     };
     if (ctx->tile == 0) fill(ctx->hcase24); else fill(ctx->hcase96);
