@@ -279,6 +279,23 @@ def test_gpu96_retry_in_every_path(engine96, numfail96):
 
 
 @pytest.mark.gpu
+def test_gpu96_retry_through_the_scaled_load_entry_point(seqeng96, engine96, numfail96):
+    """seq_mcsimulation (host buffers, per-state load scale) on the fixture's states: scale 1 must give mc_simulation's
+    results (all 67 go through the further orders with their scale), and a scale of 0.97 still converges everywhere."""
+    from powersystemsreliabilityassessment_amd import api
+    st = numfail96["matrix"]
+    u0 = engine96.retry_stats()[0]
+    d1, n1, i1 = seqeng96.seq_mcsimulation(st, 1.0, return_info=True)
+    u1 = engine96.retry_stats()[0]
+    d0, n0, i0 = engine96.mc_simulation(st, return_info=True)
+    assert u1 - u0 == 67
+    np.testing.assert_array_equal(d1, d0); np.testing.assert_array_equal(n1, n0)
+    np.testing.assert_array_equal(i1["status"], i0["status"]); np.testing.assert_array_equal(i1["iters"], i0["iters"])
+    d2, n2, i2 = seqeng96.seq_mcsimulation(st, np.full(len(st), 0.97), return_info=True)
+    assert np.all(i2["status"] == 0) and np.all(d2 <= d1 + 1e-9)
+
+
+@pytest.mark.gpu
 def test_gpu96_nonconverged_rate(engine96):
     """2e7 scenarios: the primary order ends 6.7e-7 of them non-converged (13 expected here), the further orders none
     (0 of the 67 in the first 1e8 samples, scripts/retry_soak.py)."""
