@@ -38,6 +38,10 @@ int main(int argc, char** argv)
     if (relmc_db_reset(ctx) != RELMC_OK || relmc_nsq_db_batch(ctx, 1, 0, 60000, &o, NULL, &ds) != RELMC_OK ||
         relmc_nsq_db_batch(ctx, 1, 60000, 40000, &o, &acc3, &ds) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 9; }
     if (acc3.n != acc.n || acc3.n_fail != acc.n_fail || ds.samples != 100000 || ds.rows <= 0 || ds.rows > nd) return 10;
+    /* solver bookkeeping: which static elimination order runs first (calibrated at load) and how many units went to a further one */
+    int32_t primary = -1, probe[3]; int64_t units = -1, conv = -1;
+    if (relmc_case_order(ctx, &primary, probe) != RELMC_OK || primary != 0 || probe[0] != 0) return 14;
+    if (relmc_retry_stats(ctx, &units, &conv) != RELMC_OK || units != 0 || conv != 0) return 15;
     /* the path's one collective through the library's own RCCL communicator (a single rank here: the identity) */
     uint8_t uid[RELMC_COMM_ID_BYTES]; relmc_acc red = acc;
     if (relmc_comm_unique_id(uid) != RELMC_OK || relmc_comm_init(ctx, 1, 0, uid) != RELMC_OK) { fprintf(stderr, "comm: %s\n", relmc_last_error(ctx)); return 11; }
