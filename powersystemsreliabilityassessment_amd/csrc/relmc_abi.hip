@@ -640,7 +640,6 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
         for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_nline[i] ? C.b_line[i][e] : nl) << (8 * e);
         C.b_line8[i] = pk;
         if (C.b_nline[i] > maxdeg) maxdeg = C.b_nline[i];
-        if (C.b_nline[i] > C.maxdeg_s[i / ROWL]) C.maxdeg_s[i / ROWL] = C.b_nline[i];
     }
     int nzero = 0;
     for (int k = nb; k < nb + noff; ++k) if (!has_line[k]) C.zero_off[nzero++] = (uint16_t)(4 * pos[k]);
@@ -666,9 +665,38 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
         for (int e = 0; e < 8; ++e) pk |= (uint64_t)(e < C.b_ninj[i] ? C.b_inj[i][e] : ninj) << (8 * e);
         C.b_inj8[i] = pk;
         if (C.b_ninj[i] > maxinj_) maxinj_ = C.b_ninj[i];
-        if (C.b_ninj[i] > C.maxinj_s[i / ROWL]) C.maxinj_s[i / ROWL] = C.b_ninj[i];
     }
     C.maxdeg = (uint16_t)maxdeg; C.maxinj = (uint16_t)maxinj_;
+    // ---- which lane of which bus slot holds which bus in the vector phases.  A slot's gather loops run to the longest line / injection
+    // list among its buses (two entries per step), so the partly filled second slot is given the buses with the shortest lists: the pair of
+    // list-length limits (a, b) with the fewest steps that still admits nb - RW buses.  Everything is indexed by bus, so this is free.
+    {
+        for (int q = 0; q < NBT; ++q) C.b_lane[q] = 0xff;
+        std::vector<int> slot_of(nb, 0);
+        const int n1 = nb > ROWL ? nb - ROWL : 0;
+        if (n1 > 0 && TL::BS == 2 && !getenv("RELMC_NO_BUS_MAP")) {
+            int best_a = DEGMAX, best_b = BINJMAX, best_steps = 1 << 30;
+            for (int a2 = 0; a2 <= DEGMAX; ++a2) for (int b2 = 0; b2 <= BINJMAX; ++b2) {
+                int cnt = 0;
+                for (int i = 0; i < nb; ++i) if (C.b_nline[i] <= a2 && C.b_ninj[i] <= b2) cnt++;
+                const int steps = (a2 + 1) / 2 + (b2 + 1) / 2;
+                if (cnt >= n1 && steps < best_steps) { best_steps = steps; best_a = a2; best_b = b2; }
+            }
+            std::vector<int> cand;
+            for (int i = 0; i < nb; ++i) if (C.b_nline[i] <= best_a && C.b_ninj[i] <= best_b) cand.push_back(i);
+            std::stable_sort(cand.begin(), cand.end(), [&](int x, int y) { return C.b_nline[x] + C.b_ninj[x] < C.b_nline[y] + C.b_ninj[y]; });
+            for (int k = 0; k < n1; ++k) slot_of[cand[k]] = 1;
+        } else {
+            for (int i = 0; i < nb; ++i) slot_of[i] = i / ROWL;
+        }
+        int fill[TL::BS] = {};
+        for (int i = 0; i < nb; ++i) {
+            const int t = slot_of[i];
+            C.b_lane[ROWL * t + fill[t]++] = (uint8_t)i;
+            if (C.b_nline[i] > C.maxdeg_s[t]) C.maxdeg_s[t] = C.b_nline[i];
+            if (C.b_ninj[i] > C.maxinj_s[t]) C.maxinj_s[t] = C.b_ninj[i];
+        }
+    }
     {   // is the intact network connected?  (lets the kernel skip the island search when no line is out)
         std::vector<int> lab(nb); for (int i = 0; i < nb; ++i) lab[i] = i;
         auto find = [&](int x) { while (lab[x] != x) { lab[x] = lab[lab[x]]; x = lab[x]; } return x; };

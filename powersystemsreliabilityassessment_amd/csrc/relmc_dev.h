@@ -87,6 +87,8 @@ struct DevCaseT {
     uint8_t b_inj[NBT][BINJMAX];
     int16_t b_vinj[NBT];            // virtual generator at the bus, -1 if none
     uint8_t b_ext[NBT];             // internal bus -> external bus number
+    uint8_t b_lane[NBT];            // bus held by lane r of bus slot t at [RW * t + r] (0xff = none): the partly filled last slot gets the buses with the
+                                    // shortest incidence lists, because a slot's gather loops run to the longest list among its buses (relmc_case_load)
     uint8_t b_int[NBT];             // external bus number -> internal bus
     uint32_t thr[NCOMPMAX];         // Bernoulli thresholds floor(U*2^32)
     // static schedule of the sparse block LDL' (computed once per case on the host)

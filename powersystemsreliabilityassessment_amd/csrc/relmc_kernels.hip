@@ -229,6 +229,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     uint32_t iinfo[IS];
 #pragma unroll
     for (int s = 0; s < IS; ++s) iinfo[s] = C.i_info[RW * s + rlane];
+    int vb[BS];                                   // the bus of this lane in bus slot t (>= nb: none)
+#pragma unroll
+    for (int t = 0; t < BS; ++t) vb[t] = C.b_lane[RW * t + rlane];
 
     // ---- accumulators (nsqMain.m:282-301 in per-sample form) ---------------------------
     // They live in this lane's Partial record in HBM (L2-resident, 104 B per lane) and are updated by a
@@ -443,7 +446,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 bool iso = false;
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int i = RW * t + rlane;
+                    const int i = vb[t];
                     uint32_t adj = 0;
                     if (i < nb && any_lout) {           // without a line outage no bus is isolated and the sweeps below are skipped
                         const int nlb = C.b_nline[i];
@@ -473,7 +476,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                                 if (!__any(any_lout)) break;
                                 uint32_t c = 0;
 #pragma unroll
-                                for (int t = 0; t < BS; ++t) if ((R >> (RW * t + rlane)) & 1u) c |= adjm[t];
+                                for (int t = 0; t < BS; ++t) if (vb[t] < nb && ((R >> vb[t]) & 1u)) c |= adjm[t];
                                 const uint32_t Rn = R | row_or<RW>(c);
                                 const bool ch = Rn != R;
                                 R = Rn;
@@ -520,9 +523,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int i = RW * t + rlane;
-                    if ((pinned >> i) & 1u) sf |= 1u << (14 + t);
-                    if ((dropped >> i) & 1u) sf |= 1u << (16 + t);
+                    const int i = vb[t];
+                    if (i < nb && ((pinned >> i) & 1u)) sf |= 1u << (14 + t);
+                    if (i < nb && ((dropped >> i) & 1u)) sf |= 1u << (16 + t);
                 }
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
@@ -541,7 +544,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 bool iso = false;
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int i = RW * t + rlane;
+                    const int i = vb[t];
                     if (i < nb) {
                         if (any_lout) {
                             bool anyon = false;
@@ -576,10 +579,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     for (int s = 0; s < IS; ++s) ilab[s] = LB[iinfo[s] & 0xff];
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
-                        const int i = RW * t + rlane;
+                        const int i = vb[t];
                         uint64_t roots = __ballot(i < nb && LB[i] == i);
                         while (roots) {
-                            const int pin = RW * t + (int)__builtin_ctzll(roots);      // rule 1: the island's highest bus
+                            const int pin = C.b_lane[RW * t + (int)__builtin_ctzll(roots)];      // rule 1: the island's highest bus (the bus that lane holds)
                             roots &= roots - 1;
                             uint32_t cnt = 0; double losum = 0.0; bool inI[IS];
 #pragma unroll
@@ -613,11 +616,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             nfree = row_add<RW>(nfree);
 #pragma unroll
                             for (int u = 0; u < BS; ++u)
-                                if (RW * u + rlane == pin) { sf |= 1u << (14 + u); if (!nfree) sf |= 1u << (16 + u); }   // rules 1, 5
+                                if (vb[u] == pin) { sf |= 1u << (14 + u); if (!nfree) sf |= 1u << (16 + u); }   // rules 1, 5
                         }
                     }
 #pragma unroll
-                    for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) BF[RW * t + rlane] = (B_PIN(t) ? 1 : 0) | (B_DROP(t) ? 2 : 0);
+                    for (int t = 0; t < BS; ++t) if (vb[t] < nb) BF[vb[t]] = (B_PIN(t) ? 1 : 0) | (B_DROP(t) ? 2 : 0);
                     RELOAD_FENCE();
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
@@ -647,7 +650,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             }
 #pragma unroll
             for (int t = 0; t < BS; ++t) {
-                const int i = RW * t + rlane;
+                const int i = vb[t];
                 if (i < nb) {
                     double d = C.b_bsum[i];             // every line in service: the host's sum in the same order
                     if (any_lout) {
@@ -694,7 +697,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
             }
 #pragma unroll
-            for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) Lam[RW * t + rlane] = 0.0;
+            for (int t = 0; t < BS; ++t) if (vb[t] < nb) Lam[vb[t]] = 0.0;
             niq = row_add<RW>(nq);
             fval = row_sum<RW>(fl);
             f0 = fval;
@@ -773,7 +776,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 double d00[BS], d11[BS], r0[BS], r1[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = RW * t + rlane;
+                    const int bi = vb[t];
                     d00[t] = 0; d11[t] = 0; r0[t] = 0; r1[t] = 0;
                     if (bi < nb) {
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
@@ -840,7 +843,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int z = rlane; z < nzero; z += RW) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = RW * t + rlane;
+                    const int bi = vb[t];
                     if (bi < nb) {
                         st2(W + 4 * bi, d00[t], cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11[t]);
                         st2(W + off_rhs + 2 * bi, r0[t], r1[t]);
@@ -993,7 +996,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 double dth[BS], dla[BS];
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
-                    const int bi = RW * t + rlane;
+                    const int bi = vb[t];
                     dth[t] = 0; dla[t] = 0;
                     if (bi < nb) { const d2 x = ld2(X + 2 * bi); dth[t] = x.x; dla[t] = x.y; step2 = __builtin_fma(x.x, x.x, __builtin_fma(x.y, x.y, step2)); }
                 }
@@ -1050,9 +1053,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #ifdef RELMC_TRACE
                 if (a.timing && blockIdx.x == 0 && tid < RW && it < 40) {     // debug builds: the Newton step of scenario 0, per iteration
                     double* o2 = reinterpret_cast<double*>(a.timing) + 512 + 512 * it;
-                    for (int t = 0; t < BS; ++t) { o2[RW * t + rlane] = dth[t]; o2[128 + RW * t + rlane] = dla[t]; }
+                    for (int t = 0; t < BS; ++t) if (vb[t] < nb) { o2[vb[t]] = dth[t]; o2[128 + vb[t]] = dla[t]; }
                     for (int s = 0; s < IS; ++s) o2[256 + RW * s + rlane] = dpv[s];
-                    if (it == 1) for (int t = 0; t < BS; ++t) if (RW * t + rlane < nb) (reinterpret_cast<double*>(a.timing) + 512 + 512 * 40)[RW * t + rlane] = (double)C.b_ext[RW * t + rlane];
+                    if (it == 1) for (int t = 0; t < BS; ++t) if (vb[t] < nb) (reinterpret_cast<double*>(a.timing) + 512 + 512 * 40)[vb[t]] = (double)C.b_ext[vb[t]];
                 }
 #endif
 #ifdef RELMC_ABLATE_FIXIT
@@ -1102,7 +1105,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
                         bth[t] = __builtin_fma(alphap, dth[t], bth[t]); bla[t] = __builtin_fma(alphad, dla[t], bla[t]);
-                        if (RW * t + rlane < nb) Lam[RW * t + rlane] = bla[t];
+                        if (vb[t] < nb) Lam[vb[t]] = bla[t];
                     }
                     zmu = row_sum<RW>(zl);
                     fval = row_sum<RW>(fl);
@@ -1182,7 +1185,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 if (a.nodal) {
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
-                        const int i = RW * t + rlane;
+                        const int i = vb[t];
                         if (i < nb) {
                             const int vj = C.b_vinj[i];
                             a.nodal[oidx * nb + C.b_ext[i]] = vj >= 0 ? IR[4 * vj] : 0.0;
