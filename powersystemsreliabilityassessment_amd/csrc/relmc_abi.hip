@@ -451,7 +451,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
             const uint32_t eval_d = 4u * (nl + 1) + 4u * (ninj + 1);
             uint32_t stride = C.nws > eval_d ? C.nws : eval_d;
             stride = (stride + 1u) & ~1u;
-            stride += 2u * IS * ROWL + NBT + OW / 2u;
+            stride += 2u * IS * ROWL + 2u + NBT + OW / 2u;
             while ((stride & 3u) != 2u) stride += 1;            // = the per-scenario LDS stride computed below
             static const int kGroupOfLane[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0, 1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
                                                  2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2, 3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
@@ -716,7 +716,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
     uint32_t scen = C.nws > eval_doubles ? C.nws : eval_doubles;
     scen = (scen + 1u) & ~1u;
     const uint32_t stash_off = scen;
-    scen += 2u * IS * ROWL + NBT + OW / 2u;                // stash: 1/D and Np/D per injection lane; lambda per bus; outage mask words
+    scen += 2u * IS * ROWL + 2u + NBT + OW / 2u;           // stash: 1/D and Np/D per injection lane (+ one zero pair); lambda per bus; outage mask words
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);     // tables copied to LDS; the pass schedule is read from global memory
     const uint32_t lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options

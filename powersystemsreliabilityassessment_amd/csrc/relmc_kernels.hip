@@ -193,14 +193,16 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     double* const W = reinterpret_cast<double*>(smem + OPT_BYTES + ((case_bytes + 15u) & ~15u)) + (size_t)row * a.scen_doubles;
     // The evaluation arrays ALIAS the solver workspace: they are dead once the bus gathers have been
     // taken into registers, and only then are the KKT blocks written (see "assemble" below).
-    // line record l = {g, lx, q, F} at LR + 4l, injection record j = {p, 1/D, Np/D, -} at IR + 4j; record nl / ninj
-    // is an all-zero dummy that unused gather slots point to.
+    // line record l = {g, lx, q, F} at LR + 4l; injection j: its p at IR[j], its {1/D, Np/D} in the stash pair j (the stash is indexed
+    // by injection and survives the solve, so the pair is stored once for the gathers and for the step); record nl / entry ninj is an
+    // all-zero dummy that unused gather slots point to.
     const int nlp = C.nl, nip = C.ninj;
     double* const LR = W;
     double* const IR = W + 4 * (nlp + 1);
     const int maxdeg0 = C.maxdeg_s[0], maxdeg1 = C.maxdeg_s[1], maxinj0 = C.maxinj_s[0], maxinj1 = C.maxinj_s[1];   // longest incidence lists per bus slot
     double* const Stash = W + a.stash_off + 2 * rlane;      // [IS][RW] pairs {1/D, Np/D} of this lane's injections (one b128 access each)
-    double* const Lam = W + a.stash_off + 2 * IS * RW;       // [NBT]: bus multipliers lambda_i (kept across the solve)
+    const double* const StashJ = W + a.stash_off;          // pair j of the stash, read by the bus that gathers injection j (pair IS * RW: zeros)
+    double* const Lam = W + a.stash_off + 2 * IS * RW + 2;   // [NBT]: bus multipliers lambda_i (kept across the solve)
     uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
@@ -698,6 +700,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             }
 #pragma unroll
             for (int t = 0; t < BS; ++t) if (vb[t] < nb) Lam[vb[t]] = 0.0;
+            if (rlane == 0) st2(W + a.stash_off + 2 * IS * RW, 0.0, 0.0);     // the stash pair behind the last lane's: the dummy entry when every lane holds an injection
             niq = row_add<RW>(nq);
             fval = row_sum<RW>(fl);
             f0 = fval;
@@ -755,12 +758,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         mx_z = vmax(mx_z, vmax(izp[s], izm[s]));
                         mx_lammu = vmax(mx_lammu, vmax(imup[s], imum[s]));
                     }
-                    if (j < nip) { st2(IR + 4 * j, pv, invD); IR[4 * j + 2] = npd; }
+                    if (j < nip) IR[j] = pv;
                     st2(Stash + 2 * RW * s, invD, npd);
                     SLOT_FENCE();
                 }
                 PT_MARK(1)
-                if (rlane == 0) { st2(LR + 4 * nlp, 0.0, 0.0); st2(LR + 4 * nlp + 2, 0.0, 0.0); st2(IR + 4 * nip, 0.0, 0.0); IR[4 * nip + 2] = 0.0; }
+                if (rlane == 0) { st2(LR + 4 * nlp, 0.0, 0.0); st2(LR + 4 * nlp + 2, 0.0, 0.0); IR[nip] = 0.0; }
                 // ---- assemble: gather everything the KKT blocks need into registers ... -------------
                 double vown[LS];
 #pragma unroll
@@ -805,10 +808,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         for (int e = 0; e < BINJMAX; e += 2) {
                             if (e >= (t == 0 ? maxinj0 : maxinj1)) break;
                             const int j0 = (int)((uint32_t)(pj >> (8 * e)) & 0xffu), j1 = (int)((uint32_t)(pj >> (8 * e + 8)) & 0xffu);   // unused entries name the all-zero record ninj
-                            const d2 ra0 = ld2(IR + 4 * j0), ra1 = ld2(IR + 4 * j1);
-                            const double s0 = IR[4 * j0 + 2], s1 = IR[4 * j1 + 2];
-                            bal -= ra0.x; E += ra0.y; ssum += s0;
-                            bal -= ra1.x; E += ra1.y; ssum += s1;
+                            const d2 sh0 = ld2(StashJ + 2 * j0), sh1 = ld2(StashJ + 2 * j1);
+                            const double p0 = IR[j0], p1 = IR[j1];
+                            bal -= p0; E += sh0.x; ssum += sh0.y;
+                            bal -= p1; E += sh1.x; ssum += sh1.y;
                         }
                         if (B_PIN(t)) {                   // fixed angle: identity row; its multiplier is -lx
                             d00[t] = 1.0; r0[t] = 0.0;
