@@ -217,13 +217,16 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // Loop-invariant per-lane table values kept in registers where that was measured to pay (the compiler spills colder values to scratch
     // instead, i.e. to the idle vector-memory path): susceptance and rating of the lane's lines on both tiles (-0.9 % / -1.9 %), the
     // injection bounds on the wide tile (-1.8 %; +0.6 % on the narrow one).  Cost and incidence lists in registers: neutral / +14 %.
+    // ... per instantiation: the instantiations that write per-scenario results or walk the chronology (MODE 1, 2, 4) carry more live state
+    // and lose 2-3 % with the line values in registers (measured on MODE 1 and 2), the fused ones gain 1-2 %
+    constexpr bool LTAB_LDS = (MODE == 1 || MODE == 2 || MODE == 4);
     double lbv_[LS], lrv_[LS], ihi_[IS], ilo_[IS];
 #pragma unroll
-    for (int s = 0; s < LS; ++s) { lbv_[s] = MODE == 2 ? 0.0 : TABL.l_b[RW * s + rlane]; lrv_[s] = MODE == 2 ? 0.0 : TABL.l_rate[RW * s + rlane]; }
+    for (int s = 0; s < LS; ++s) { lbv_[s] = LTAB_LDS ? 0.0 : TABL.l_b[RW * s + rlane]; lrv_[s] = LTAB_LDS ? 0.0 : TABL.l_rate[RW * s + rlane]; }
 #pragma unroll
     for (int s = 0; s < IS; ++s) { ihi_[s] = RW == 64 ? TABI.i_tab[RW * s + rlane][0] : 0.0; ilo_[s] = RW == 64 ? TABI.i_tab[RW * s + rlane][1] : 0.0; }
-#define lb(s) (MODE == 2 ? TABL.l_b[RW * (s) + rlane] : lbv_[s])      /* the sequential instantiation carries more live state: registers cost it more than the reads */
-#define lr(s) (MODE == 2 ? TABL.l_rate[RW * (s) + rlane] : lrv_[s])
+#define lb(s) (LTAB_LDS ? TABL.l_b[RW * (s) + rlane] : lbv_[s])
+#define lr(s) (LTAB_LDS ? TABL.l_rate[RW * (s) + rlane] : lrv_[s])
 #define IHL(s, j) (RW == 64 ? d2{ihi_[s], ilo_[s]} : ld2(TABI.i_tab[j]))
 #define ICOST(s, j) TABI.i_tab[j][2]
 #define PLIST(t, bi) TABG.b_line8[bi]
