@@ -272,7 +272,7 @@ def rts96_fixture(n_sample):
 
 def rts96_numfail_fixture(scan_json):
     """States of a 1e8-sample RTS-96 run (seed 1) on which the DEVICE solver ended "numerically failed"
-    (scripts/numfail96.py on the GPU box; its JSON carries the device's and the C oracle's results): here the numpy MIPS
+    (tests/tools/numfail96.py on the GPU box; its JSON carries the device's and the C oracle's results): here the numpy MIPS
     restatement and the HiGHS LP value are added, so the fixture pins what the oracles say about exactly these states."""
     with open(scan_json) as f:
         scan = json.load(f)
@@ -282,7 +282,7 @@ def rts96_numfail_fixture(scan_json):
         res1 = pool.map(_eval96, [(l, po.PHYSICAL) for l in lists], chunksize=2)
     by = {(x["policy"], tuple(x["failed"])): x for x in scan["states"]}
     out = dict(description="RTS-96 states (seed 1, first 1e8 samples) where the device solver's status was NUMFAIL; per policy: numpy MIPS "
-                           "(status/iters/dns), HiGHS LP value, C oracle and device results as scanned on the GPU box by scripts/numfail96.py",
+                           "(status/iters/dns), HiGHS LP value, C oracle and device results as scanned on the GPU box by tests/tools/numfail96.py",
                n_scanned=scan["n_scanned"], seed=scan["seed"], states=[])
     for l, a, b in zip(lists, res0, res1):
         ent = dict(failed=list(l))
@@ -304,7 +304,7 @@ if __name__ == "__main__":
     ap.add_argument("--n-nsq", type=int, default=100000)
     ap.add_argument("--only-seq", action="store_true")
     ap.add_argument("--only-rts96", action="store_true")
-    ap.add_argument("--numfail96", default="", help="scan JSON of scripts/numfail96.py -> rts96_numfail_fixture.json")
+    ap.add_argument("--numfail96", default="", help="scan JSON of tests/tools/numfail96.py -> rts96_numfail_fixture.json")
     a = ap.parse_args()
     if a.numfail96:
         rts96_numfail_fixture(a.numfail96)

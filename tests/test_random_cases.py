@@ -112,7 +112,7 @@ def test_random_case_matches_oracle(spec):
 
 
 def test_order_calibration_on_a_case_the_default_order_dislikes():
-    """Case 8 of scripts/fuzz_cases.py (7 buses, 8 lines): the default static elimination order ends 6 % of its states
+    """Case 8 of tests/tools/fuzz_cases.py (7 buses, 8 lines): the default static elimination order ends 6 % of its states
     non-converged.  relmc_case_load notices on its 8192 calibration states, probes the two further orders and makes the best one
     the primary; what is left goes through the retry levels, and the results are the oracle's."""
     from oracle import coracle

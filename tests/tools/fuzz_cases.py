@@ -1,7 +1,7 @@
 """Fuzz run over random networks (the generator of tests/test_random_cases.py, other seeds and sizes): device against the C oracle on
 sampled states, both policies; prints one line per case and every disagreement in status, dns (> 1e-5 MW) or iterations (> 1)."""
 import importlib.util, os, sys, time
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 import numpy as np
 spec = importlib.util.spec_from_file_location("trc", os.path.join(ROOT, "tests/test_random_cases.py"))

@@ -4,7 +4,7 @@ the kernel does, here in numpy), and the latter with the soft injection of every
 residual of the UNREDUCED KKT system per block of rows.  CPU only; developer tool (uses the numpy oracle)."""
 import os, sys
 import numpy as np
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 from oracle import pyoracle as po
 

@@ -1,7 +1,7 @@
 """Newton steps of one state, device (RELMC_TRACE build) against the numpy MIPS restatement (pivoted LU of the unreduced system):
 per iteration the largest relative difference of dtheta, dlambda, dp and where it sits.  usage: step_compare.py <nb> <state index>"""
 import os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 sys.path.insert(0, ROOT)
 os.environ.setdefault("RELMC_LIB_PATH", os.path.join(ROOT, "powersystemsreliabilityassessment_amd/csrc/ablate/librelmc_trace.so"))
 import ctypes as C
