@@ -310,7 +310,7 @@ int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* con
 int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t probe_failures_out[3]);
 
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
-/* Batches of up to 131072 samples (the reference's is 100, nsqMain.m:60) are evaluated many at a time in the modes
+/* Batches of up to 8192 samples (the reference's is 100, nsqMain.m:60) are evaluated many at a time in the modes
  * distinct_states = 0 and 2; every checkpoint's history entry and the stopping point are those of the batch-by-batch loop
  * (DESIGN.md 6.8).  RELMC_NSQ_NO_STRETCH=1 in the environment forces one launch per batch (diagnosis). */
 int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);

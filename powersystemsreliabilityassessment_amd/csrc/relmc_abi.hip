@@ -2026,12 +2026,14 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     // the dns of each of its samples; the four indices of every checkpoint inside it (nsqMain.m:286-301 need only the dns
     // sums and the loss count) follow on the host.  If beta reaches its limit inside the stretch, the stretch is cut at that
     // checkpoint and taken again over the shorter range (the database is first put back to its rows and counts of before
-    // the stretch), so that the result is the one of the batch-by-batch loop.
-    constexpr int64_t kStretch = 1 << 18;
-    if ((o->distinct_states == 0 || o->distinct_states == 2) && o->batch <= kStretch / 2 &&
+    // the stretch), so that the result is the one of the batch-by-batch loop.  Only for batches whose launch is overhead-bound (a launch
+    // costs 0.2-0.4 ms whatever its size, i.e. as much as 1e4 scenarios), and with stretches that grow with the samples already drawn
+    // (256 batches at first, then as many samples as the run holds, up to 2^18): what a cut throws away stays in proportion to the run.
+    constexpr int64_t kStretch = 1 << 18, kStretchMaxBatch = 8192;
+    if ((o->distinct_states == 0 || o->distinct_states == 2) && o->batch <= kStretchMaxBatch &&
         !std::getenv("RELMC_NSQ_NO_STRETCH") /* diagnosis: one launch per batch */) {
         const bool use_db = o->distinct_states == 2;
-        const int64_t per = kStretch / o->batch * o->batch;
+        const int64_t per = kStretch / o->batch * o->batch;       // buffer size = longest stretch
         HIP_TRY(ctx, hipSetDevice(ctx->device));
         if (ctx->hist_cap < per) {
             if (ctx->dhist) (void)hipFree(ctx->dhist);
@@ -2043,7 +2045,9 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         }
         const double* const hd = ctx->hhist;
         while (beta > o->beta_limit && done < o->max_samples) {
-            const int64_t m = (o->max_samples - done) < per ? (o->max_samples - done) : per;
+            int64_t len = done > 256 * o->batch ? done / o->batch * o->batch : 256 * o->batch;
+            if (len > per) len = per;
+            const int64_t m = (o->max_samples - done) < len ? (o->max_samples - done) : len;
             relmc_acc part;
             int rc;
             const int64_t rows0 = ctx->db_n, samples0 = ctx->db_samples;
