@@ -204,10 +204,13 @@ int finish_timing(relmc_ctx* ctx)
 // order of the sparse block LDL' (level-then-min-fill, reference bus last), symbolic fill, the
 // static task schedule the kernel interprets, incidence lists, thresholds.  Mirrors what
 // nsqMain.m:42-167 prepares once before its Monte Carlo loop.
+// case_symbolic is pure host arithmetic (no HIP call): relmc_debug_symbolic runs it without a device, which is how the CPU test suite
+// checks every schedule it produces by interpreting it against a dense solve (tests/test_schedule.py).
+struct SymGeom { uint32_t stash_off = 0, scen_doubles = 0, lds_bytes = 0; long conflict_before = 0, conflict_after = 0; };
+
 template <class TL>
-int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant = 0)
+int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant, SymGeom& geom)
 {
-    const bool alt = order_variant != 0;            // the alternate image: geometry into the alt_* fields, nothing else of the context changes
     constexpr int NBT = TL::NBT, NLT = TL::NLT, NIT = TL::NIT, NCOMPMAX = TL::NCOMPMAX, MAXOFF = TL::MAXOFF, MAXPASS = TL::MAXPASS,
                   ROWL = TL::RW, IS = TL::IS, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     const int nb = d->nb, ng = d->ng, nl = d->nl, nd = d->nd, ninj = ng + nd, ncomp = ng + nl;
@@ -546,7 +549,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
                     if (c2 <= pc[p]) { total += c2 - pc[p]; pc[p] = c2; } else std::swap(pass_tasks[p][i], pass_tasks[p][j]);
                 }
             }
-            ctx->conflict_before = before; ctx->conflict_after = total;
+            geom.conflict_before = before; geom.conflict_after = total;
             if (getenv("RELMC_VERBOSE")) fprintf(stderr, "relmc: placement search %.1f ms\n", std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t_place0).count());
             for (int p = 0; p < np; ++p)
                 for (int r = 0; r < ROWL; ++r) {
@@ -720,8 +723,25 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);     // tables copied to LDS; the pass schedule is read from global memory
     const uint32_t lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
-    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (lds_bytes > 160u * 1024u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
+    geom.stash_off = stash_off; geom.scen_doubles = scen; geom.lds_bytes = lds_bytes;
+    return RELMC_OK;
+}
+
+template <class TL>
+int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant = 0)
+{
+    const bool alt = order_variant != 0;            // the alternate image: geometry into the alt_* fields, nothing else of the context changes
+    constexpr int WPB = TL::WPB;
+    SymGeom geom;
+    {
+        const int rc = case_symbolic<TL>(ctx, d, C, order_variant, geom);
+        if (rc) return rc;
+    }
+    const uint32_t stash_off = geom.stash_off, scen = geom.scen_doubles, lds_bytes = geom.lds_bytes;
+    const int nb = d->nb, ng = d->ng, nl = d->nl, ncomp = ng + nl;
+    if (!alt) { ctx->conflict_before = geom.conflict_before; ctx->conflict_after = geom.conflict_after; }
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (alt) {
         const int v = order_variant - 1;
         if (!ctx->dcase_alt[v]) HIP_TRY(ctx, hipMalloc(&ctx->dcase_alt[v], sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)));
@@ -2269,6 +2289,45 @@ int32_t relmc_debug_schedule(const relmc_ctx* ctx, int32_t* out9)
     };
     if (ctx->tile == 0) fill(ctx->hcase24); else fill(ctx->hcase96);
     return RELMC_OK;
+}
+
+// Host-only introspection (no device, no context): the symbolic analysis and static solver schedule relmc_case_load would build for this
+// case under elimination order `order_variant` (0 = primary).  tests/test_schedule.py interprets the schedule on the CPU against a dense
+// solve, which is how every ordering / scheduling change is checked before it reaches a GPU.
+//   hdr[24]: tile (0 = 16-lane rows, 1 = 64-lane rows), RW, nb, noff, nws, off_rhs, npass, npass_upd, npass_inv, npass_updh, npass_updq,
+//            nzero, scen_doubles, lds_bytes, modelled LDS conflict cycles before / after the placement search, MAXPASS, nl, 6 spare
+//   tasks[npass][RW][4] (0xffff = no task), pass_ntask[npass], b_int[nb] (external -> internal bus), l_blk[nl] (W offset of the owner
+//   line's block, 0xffff otherwise), l_info[nl] (from | to << 8 | flags << 24, internal bus numbers), zero_off[nzero]
+int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, int32_t* hdr, uint16_t* tasks, int64_t tasks_cap, uint8_t* pass_ntask,
+                             uint8_t* b_int, uint16_t* l_blk, uint32_t* l_info, uint16_t* zero_off, char* err, int32_t err_cap)
+{
+    if (!d || !hdr || !tasks || !pass_ntask || !b_int || !l_blk || !l_info || !zero_off) return RELMC_ERR_INVALID;
+    auto ctx = std::make_unique<relmc_ctx>();              // host-side use only: collects the error text
+    SymGeom g;
+    int rc;
+    auto dump = [&](const auto& C, int tile, int rw, int maxpass) {
+        for (int k = 0; k < 24; ++k) hdr[k] = 0;
+        hdr[0] = tile; hdr[1] = rw; hdr[2] = C.nb; hdr[3] = C.noff; hdr[4] = (int)C.nws; hdr[5] = C.off_rhs; hdr[6] = C.npass; hdr[7] = C.npass_upd;
+        hdr[8] = C.npass_inv; hdr[9] = C.npass_updh; hdr[10] = C.npass_updq; hdr[11] = C.nzero; hdr[12] = (int)g.scen_doubles; hdr[13] = (int)g.lds_bytes;
+        hdr[14] = (int)g.conflict_before; hdr[15] = (int)g.conflict_after; hdr[16] = maxpass; hdr[17] = C.nl;
+        if ((int64_t)C.npass * rw * 4 > tasks_cap) return (int)RELMC_ERR_INVALID;
+        for (int p = 0; p < C.npass; ++p) { pass_ntask[p] = C.pass_ntask[p]; for (int r = 0; r < rw; ++r) for (int k = 0; k < 4; ++k) tasks[((size_t)p * rw + r) * 4 + k] = C.task[p][r][k]; }
+        for (int i = 0; i < C.nb; ++i) b_int[i] = C.b_int[i];
+        for (int l = 0; l < C.nl; ++l) { l_info[l] = C.l_info[l]; l_blk[l] = ((C.l_info[l] >> 24) & LF_OWNER) ? C.l_blk[l] : (uint16_t)0xffff; }
+        for (int z = 0; z < C.nzero; ++z) zero_off[z] = C.zero_off[z];
+        return (int)RELMC_OK;
+    };
+    if (d->nb <= Tile24::NBT && d->nl <= Tile24::NLT && d->ng + d->nd <= Tile24::NIT && d->ng + d->nl <= Tile24::NCOMPMAX) {
+        auto C = std::make_unique<DevCaseT<Tile24>>();
+        rc = case_symbolic<Tile24>(ctx.get(), d, *C, order_variant, g);
+        if (rc == RELMC_OK) rc = dump(*C, 0, Tile24::RW, Tile24::MAXPASS);
+    } else {
+        auto C = std::make_unique<DevCaseT<Tile96>>();
+        rc = case_symbolic<Tile96>(ctx.get(), d, *C, order_variant, g);
+        if (rc == RELMC_OK) rc = dump(*C, 1, Tile96::RW, Tile96::MAXPASS);
+    }
+    if (err && err_cap > 0) { std::strncpy(err, ctx->err.c_str(), (size_t)err_cap - 1); err[err_cap - 1] = 0; }
+    return rc;
 }
 
 // profiling hook (only meaningful in -DRELMC_PHASE_TIMING builds): per-phase cycle sums of the last launch

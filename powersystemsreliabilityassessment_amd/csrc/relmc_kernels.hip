@@ -91,15 +91,23 @@ template <int RW> DEVFI bool row_any(bool p, int lane)
     else return ((b >> (lane & 48)) & 0xffffull) != 0;
 }
 
-// 1/x to ~1 ulp: v_rcp_f64 + two Newton steps (no IEEE division sequence)
+// 1/x to ~1 ulp (no IEEE division sequence): v_rcp_f64 is good to 4.4e-8 (measured on gfx950); with e = 1 - x r the exact reciprocal is
+// r (1 + e + e^2 + ...), so ONE cubic correction r (1 + e + e^2) leaves e^3 ~ 1e-22 and a single final rounding -- three FMAs where two
+// quadratic Newton steps take four (round 3: -0.6 % / -2.1 % kernel time on RTS-24 / RTS-96, results bit-identical to the two-step form)
 DEVFI double frcp(double x)
 {
-    double r = __builtin_amdgcn_rcp(x);
-    double e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    e = __builtin_fma(-x, r, 1.0);
-    r = __builtin_fma(r, e, r);
-    return r;
+    const double r = __builtin_amdgcn_rcp(x);
+    const double e = __builtin_fma(-x, r, 1.0);
+    return __builtin_fma(r, __builtin_fma(e, e, e), r);
+}
+// 1/a and 1/b from ONE reciprocal: R = 1/(a b), 1/a = b R, 1/b = a R -- a v_rcp_f64 is quarter rate and wants its correction, two
+// multiplications are cheaper.  Used for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of a two-sided bound: all positive and
+// between ~1e-16 and ~1e6, so the product neither overflows nor underflows; ~2 ulp instead of ~1 (round 3: a further -1.5 % / -0.8 %;
+// 1 of the 878 + 1 of the 317 fixture states move by one iteration, dns unchanged to 2e-7 MW)
+DEVFI void frcp_pair(double a, double b, double& ra, double& rb)
+{
+    const double R = frcp(a * b);
+    ra = b * R; rb = a * R;
 }
 
 // 1/x to ~2e-15 relative (measured on gfx950: raw v_rcp_f64 4.4e-8, one Newton step 2.0e-15, two steps exact):
@@ -108,6 +116,11 @@ DEVFI double frcp1(double x)
 {
     const double r = __builtin_amdgcn_rcp(x);
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
+}
+DEVFI void frcp1_pair(double a, double b, double& ra, double& rb)
+{
+    const double R = frcp1(a * b);
+    ra = b * R; rb = a * R;
 }
 
 // Philox4x32-10 (Salmon et al. SC'11); counter (i_lo, i_hi, block, 0), key = seed
@@ -729,7 +742,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (L_ACT(s)) {
                         const double b = lb(s), rr = lr(s);
                         const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
-                        const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
+                        double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
                         g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
                         lx = __builtin_fma(b, lmup[s] - lmum[s], lx);
                         q = b * ((lmup[s] * hp + gamma) * rzp - (lmum[s] * hm + gamma) * rzm);
@@ -751,7 +764,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (I_BOX(s)) {
                         const d2 hl = IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
-                        const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
+                        double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
                         const double D = imup[s] * rzp + imum[s] * rzm;
                         const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
@@ -1008,7 +1021,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
                 // Two passes over the slack/multiplier steps: pass 1 only finds the step lengths (ratio
                 // tests), pass 2 recomputes dz, dmu and applies them.  Recomputing ~150 VALU instructions
-                // keeps 72 VGPRs free, which is what lets two wavefronts share a SIMD.
+                // keeps 72 VGPRs free, which is what lets two wavefronts share a SIMD.  Measured alternatives (round 3, profiles/r3_rcp/):
+                // 1/z of the evaluation kept for both passes (14 doubles per lane that the allocator parks in scratch across the solver
+                // passes): +11.6 % / +11.2 % kernel time on RTS-24 / RTS-96 -- the reloads sit on the wavefront's critical path; dmu of
+                // pass 1 kept for pass 2: neutral (the 14 doubles are spilled again); the full-step-slack form dz = (r - (F + dF)) - z
+                // (three adds less per pair): WRONG -- F + dF absorbs a step of 1e-12 into a flow of O(1), the slack of an active limit
+                // (1e-10) then carries a relative error of 1e-6 and 1 % of the scenarios never converge; -h - z - dh keeps small with small.
                 double tp = 0.0, td = 0.0;        // max over inequality rows of -dz/z and -dmu/mu
                 double dF[LS], dG[LS];
 #pragma unroll
@@ -1022,12 +1040,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                            const double rzp = frcp(lzp[s]), rzm = frcp(lzm[s]);
+                            double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
                             const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
                             const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
                             // ratio tests without divisions by the steps: min_k z_k/(-dz_k) = 1 / max_k(-dz_k/z_k)
                             tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
-                            td = vmax(td, vmax(-dmup * frcp1(lmup[s]), -dmum * frcp1(lmum[s])));
+                            double rmp, rmm; frcp1_pair(lmup[s], lmum[s], rmp, rmm);
+                            td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                         }
                     }
                     SLOT_FENCE();
@@ -1045,11 +1064,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                            const double rzp = frcp(izp[s]), rzm = frcp(izm[s]);
+                            double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
                             const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
                             tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
-                            td = vmax(td, vmax(-dmup * frcp1(imup[s]), -dmum * frcp1(imum[s])));
+                            double rmp, rmm; frcp1_pair(imup[s], imum[s], rmp, rmm);
+                            td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
@@ -1081,8 +1101,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * frcp(lzp[s]);
-                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * frcp(lzm[s]);
+                            double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
+                            const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
+                            const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
                             lzp[s] = __builtin_fma(alphap, dzp, lzp[s]); lzm[s] = __builtin_fma(alphap, dzm, lzm[s]);
                             lmup[s] = __builtin_fma(alphad, dmup, lmup[s]); lmum[s] = __builtin_fma(alphad, dmum, lmum[s]);
                             zl = __builtin_fma(lzp[s], lmup[s], zl); zl = __builtin_fma(lzm[s], lmum[s], zl);
@@ -1098,8 +1119,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * frcp(izp[s]);
-                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * frcp(izm[s]);
+                            double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
+                            const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
+                            const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
                             ip[s] = __builtin_fma(alphap, dpv[s], ip[s]);
                             izp[s] = __builtin_fma(alphap, dzp, izp[s]); izm[s] = __builtin_fma(alphap, dzm, izm[s]);
                             imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
