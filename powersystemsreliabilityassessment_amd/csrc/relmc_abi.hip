@@ -357,6 +357,11 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
                     const int j = succ[i][k];
                     if (tasks[j].kind == tasks[i].kind && depth[j] + succw[i][k] > depth[i]) depth[i] = depth[j] + succw[i][k];
                 }
+            if (getenv("RELMC_VERBOSE")) {         // longest dependency chain per phase = the fewest passes any packing could reach
+                int md[3] = {0, 0, 0};
+                for (int i = 0; i < nt; ++i) if (depth[i] + 1 > md[tasks[i].kind]) md[tasks[i].kind] = depth[i] + 1;
+                fprintf(stderr, "relmc: order %d: critical path (passes) update %d, inversion %d, back substitution %d\n", order_variant, md[0], md[1], md[2]);
+            }
             // A pass costs its LDS instructions whatever its fill, and an update pass filled to at most a half / a quarter runs in the
             // cheaper half / quarter form (relmc_dev.h): 10 / 7 / 6 instructions.  So the update phase is scheduled twice or more: with
             // the full row width throughout, and with only half of it from pass F on; the cheapest variant that needs no extra pass wins.
@@ -605,6 +610,7 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
             if (q > 0 && pkind[q] < pkind[q - 1]) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: schedule phases out of order");
         }
         C.npass_upd = (uint16_t)nu; C.npass_inv = (uint16_t)ni;
+        if (getenv("RELMC_VERBOSE")) { fprintf(stderr, "relmc: order %d: %d + %d + %d passes, tasks per pass:", order_variant, nu, ni, (int)pkind.size() - nu - ni); for (size_t q = 0; q < pkind.size(); ++q) fprintf(stderr, " %d", pcount[q]); fprintf(stderr, "\n"); }
     }
 
     // ---- lines
