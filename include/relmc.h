@@ -217,7 +217,13 @@ int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
  *   relmc_db_accumulate  the accumulators of the whole database again (no sampling)
  *   relmc_db_size        rows and samples held
  *   relmc_db_export      rows [first_row, first_row + n_rows) in the reference's column layout; any output may be NULL:
- *                        states[n x (ng+nl)], count[n], dns[n], flag[n] (dns > 1e-4, :270), nodal[n x nb], status[n], iters[n] */
+ *                        states[n x (ng+nl)], count[n], dns[n], flag[n] (dns > 1e-4, :270), nodal[n x nb], status[n], iters[n],
+ *                        relaxed[n] (1 = an island rule relaxed Pmin or decommitted units: the row counts in n_infeasible)
+ *   relmc_db_import      resume: exported rows back into an EMPTY database, same order (the table of row ids is rebuilt); the next
+ *                        relmc_nsq_db_batch / relmc_nsq_run(distinct_states = 2) continues as if the run had never stopped.
+ *                        opts = the solver options the rows were computed under (NULL = defaults); status / iters / relaxed may be NULL
+ * After an error return of relmc_nsq_db_batch on a non-empty database the counts of known rows may have advanced without their
+ * samples: the database then refuses every call but relmc_db_reset (and relmc_case_load) with RELMC_ERR_INVALID. */
 typedef struct {
     int64_t rows;             /* distinct states in the database (database_row_count)     */
     int64_t samples;          /* samples they stand for (sum of the count column)          */
@@ -231,7 +237,11 @@ int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, 
 int32_t relmc_db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out);
 int32_t relmc_db_size(const relmc_ctx* ctx, int64_t* rows_out, int64_t* samples_out);
 int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8_t* states_host, int64_t* count_host,
-                        double* dns_host, int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host);
+                        double* dns_host, int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host,
+                        uint8_t* relaxed_host);
+int32_t relmc_db_import(relmc_ctx* ctx, const relmc_solver_opts* opts, int64_t n_rows, const uint8_t* states_host,
+                        const int64_t* count_host, const double* dns_host, const double* nodal_host, const int32_t* status_host,
+                        const int32_t* iters_host, const uint8_t* relaxed_host);
 
 /* ---- multi-GPU: the path's single collective (the reference's parfor, nsqMain.m:257-263) ------------ */
 /* One process per GPU, one context per process.  Scenarios shard by global index (any contiguous split of
@@ -303,6 +313,11 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
  * units re-evaluated, and how many of them ended converged (or MATPOWER-singular).  RELMC_NO_RETRY=1 in the environment turns the
  * second attempt off (diagnosis). */
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);
+/* The kernel's list of non-converged units holds 4096 + (units of the call) / 256 entries.  relmc_nsq_accumulate / relmc_nsq_run
+ * (every sample solved) evaluate a chunk again with a longer list if it overflows; the other entry points leave the units beyond the
+ * list with their first-attempt results and count them here (0 on every case relmc_case_load calibrated: its primary order fails on at
+ * most 0.1 % of the states). */
+int32_t relmc_retry_overflow(const relmc_ctx* ctx, int64_t* units_out);
 /* relmc_case_load evaluates 8192 sampled states under the primary static order; a case on which more than 0.1 % of them end
  * non-converged gets the further orders probed on the same sample and the best of the three as its primary.  primary_out: 0 = the
  * default (level-then-fill), 1 = the same with the ties broken the other way, 2 = fill first; probe_failures_out: failures of each

@@ -172,6 +172,12 @@ function retry_stats(eng::Engine)
     check(ccall((:relmc_retry_stats, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}, Ref{Int64}), eng.h, u, c), eng.h, "relmc_retry_stats")
     return (u[], c[])
 end
+"units that did not fit the kernel's list of non-converged units and kept their first-attempt results (relmc_retry_overflow)"
+function retry_overflow(eng::Engine)
+    u = Ref{Int64}(0)
+    check(ccall((:relmc_retry_overflow, LIB), Int32, (Ptr{Cvoid}, Ref{Int64}), eng.h, u), eng.h, "relmc_retry_overflow")
+    return u[]
+end
 "(primary static elimination order 0/1/2, failures of each probed order among the 8192 calibration states; -1 = not probed)"
 function case_order(eng::Engine)
     p = Ref{Int32}(0); f = zeros(Int32, 3)
@@ -199,9 +205,19 @@ function db_export(eng::Engine, first_row::Integer, n_rows::Integer)
     states = Matrix{UInt8}(undef, ncomp, n_rows); count = Vector{Int64}(undef, n_rows); dns = Vector{Float64}(undef, n_rows)
     flag = Vector{Int32}(undef, n_rows); nodal = Matrix{Float64}(undef, nb, n_rows)
     check(ccall((:relmc_db_export, LIB), Int32,
-                (Ptr{Cvoid}, Int64, Int64, Ptr{UInt8}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}),
-                eng.h, first_row, n_rows, states, count, dns, flag, nodal, C_NULL, C_NULL), eng.h, "relmc_db_export")
+                (Ptr{Cvoid}, Int64, Int64, Ptr{UInt8}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Ptr{UInt8}),
+                eng.h, first_row, n_rows, states, count, dns, flag, nodal, C_NULL, C_NULL, C_NULL), eng.h, "relmc_db_export")
     return hcat(Float64.(permutedims(states)), Float64.(count), dns, Float64.(flag), permutedims(nodal))     # the reference's matrix
+end
+
+"Resume: a state_database matrix in the reference's column layout (as db_export returns it) back into the EMPTY database."
+function db_import(eng::Engine, db::AbstractMatrix{Float64}; mpopt::SolverOpts = mpoption())
+    ncomp = eng.sys.ng + eng.sys.nl; nb = eng.sys.nb; n = size(db, 1)
+    states = Matrix{UInt8}(permutedims(db[:, 1:ncomp] .!= 0)); count = Vector{Int64}(round.(Int64, db[:, ncomp + 1]))
+    dns = Vector{Float64}(db[:, ncomp + 2]); nodal = Matrix{Float64}(permutedims(db[:, ncomp + 4:ncomp + 3 + nb]))
+    check(ccall((:relmc_db_import, LIB), Int32,
+                (Ptr{Cvoid}, Ref{SolverOpts}, Int64, Ptr{UInt8}, Ptr{Int64}, Ptr{Cdouble}, Ptr{Cdouble}, Ptr{Int32}, Ptr{Int32}, Ptr{UInt8}),
+                eng.h, mpopt, n, states, count, dns, nodal, C_NULL, C_NULL, C_NULL), eng.h, "relmc_db_import")
 end
 
 # ---- multi-GPU: one process per GPU (Distributed / MPI.jl), ONE RCCL all-reduce of the accumulators per convergence check ---

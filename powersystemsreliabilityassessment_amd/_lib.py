@@ -24,8 +24,8 @@ EXPORTS = [
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
     "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy",
-    "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export",
-    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_case_order",
+    "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
+    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_case_order",
 ]
 
 
@@ -121,10 +121,14 @@ def load():
     L.relmc_db_size.restype = C.c_int32
     L.relmc_retry_stats.argtypes = [vp, _abi.c_int64_p, _abi.c_int64_p]
     L.relmc_retry_stats.restype = C.c_int32
+    L.relmc_retry_overflow.argtypes = [vp, _abi.c_int64_p]
+    L.relmc_retry_overflow.restype = C.c_int32
     L.relmc_case_order.argtypes = [vp, i32p, i32p]
     L.relmc_case_order.restype = C.c_int32
-    L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p]
+    L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p, u8p]
     L.relmc_db_export.restype = C.c_int32
+    L.relmc_db_import.argtypes = [vp, C.c_void_p, C.c_int64, u8p, _abi.c_int64_p, dp, dp, i32p, i32p, u8p]
+    L.relmc_db_import.restype = C.c_int32
     if hasattr(L, "relmc_dpp_probe"):
         L.relmc_dpp_probe.argtypes = [vp, dp, dp]
         L.relmc_dpp_probe.restype = C.c_int32

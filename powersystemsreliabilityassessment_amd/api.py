@@ -268,6 +268,12 @@ class Engine:
                                               C.byref(st)), "relmc_nsq_db_batch")
         return acc, st
 
+    def db_accumulate(self) -> _abi.Acc:
+        """The accumulators of the whole database again (nsqMain.m:282-301 over every row; no sampling)."""
+        acc = _abi.Acc()
+        self._check(self.L.relmc_db_accumulate(self._h, C.byref(acc)), "relmc_db_accumulate")
+        return acc
+
     def db_size(self):
         rows, samples = C.c_int64(), C.c_int64()
         self._check(self.L.relmc_db_size(self._h, C.byref(rows), C.byref(samples)), "relmc_db_size")
@@ -279,6 +285,12 @@ class Engine:
         u, c = C.c_int64(), C.c_int64()
         self._check(self.L.relmc_retry_stats(self._h, C.byref(u), C.byref(c)), "relmc_retry_stats")
         return int(u.value), int(c.value)
+
+    def retry_overflow(self) -> int:
+        """Units that did not fit the kernel's list of non-converged units and kept their first-attempt results (relmc_retry_overflow)."""
+        u = C.c_int64()
+        self._check(self.L.relmc_retry_overflow(self._h, C.byref(u)), "relmc_retry_overflow")
+        return int(u.value)
 
     def case_order(self):
         """(primary static elimination order 0/1/2, failures of each probed order among the 8192 calibration states; -1 = not
@@ -295,13 +307,31 @@ class Engine:
         nc, nb = self.case.ncomp, self.case.nb
         out = dict(states=np.zeros((n, nc), dtype=np.uint8), count=np.zeros(n, dtype=np.int64), dns=np.zeros(n),
                    flag=np.zeros(n, dtype=np.int32), nodal=np.zeros((n, nb)), status=np.zeros(n, dtype=np.int32),
-                   iters=np.zeros(n, dtype=np.int32))
+                   iters=np.zeros(n, dtype=np.int32), relaxed=np.zeros(n, dtype=np.uint8))
         self._check(self.L.relmc_db_export(self._h, int(first_row), n, out["states"].ctypes.data_as(_abi.c_uint8_p),
                                            out["count"].ctypes.data_as(_abi.c_int64_p), out["dns"].ctypes.data_as(_abi.c_double_p),
                                            out["flag"].ctypes.data_as(_abi.c_int32_p), out["nodal"].ctypes.data_as(_abi.c_double_p),
-                                           out["status"].ctypes.data_as(_abi.c_int32_p), out["iters"].ctypes.data_as(_abi.c_int32_p)),
+                                           out["status"].ctypes.data_as(_abi.c_int32_p), out["iters"].ctypes.data_as(_abi.c_int32_p),
+                                           out["relaxed"].ctypes.data_as(_abi.c_uint8_p)),
                     "relmc_db_export")
         return out
+
+    def db_import(self, rows: dict, mpopt=None):
+        """Resume: the rows of an earlier `db_export()` (same case) back into the EMPTY database, in the same order; `mpopt` = the solver
+        options they were computed under.  The next `nsq_db_batch` / `nsqMain(distinct_states=2)` continues the run."""
+        o = mpopt if mpopt is not None else mpoption()
+        f = lambda a, dt: np.ascontiguousarray(a, dtype=dt)
+        st, cnt, dns, nod = f(rows["states"], np.uint8), f(rows["count"], np.int64), f(rows["dns"], np.float64), f(rows["nodal"], np.float64)
+        n = st.shape[0]
+        if st.shape != (n, self.case.ncomp) or nod.shape != (n, self.case.nb) or cnt.shape != (n,) or dns.shape != (n,):
+            raise ValueError("db_import: rows do not have the loaded case's shapes")
+        opt = lambda k, dt, pt: (f(rows[k], dt), pt) if k in rows and rows[k] is not None else (None, None)
+        stat, _ = opt("status", np.int32, None); its, _ = opt("iters", np.int32, None); rel, _ = opt("relaxed", np.uint8, None)
+        self._check(self.L.relmc_db_import(self._h, C.byref(o), n, st.ctypes.data_as(_abi.c_uint8_p), cnt.ctypes.data_as(_abi.c_int64_p),
+                                           dns.ctypes.data_as(_abi.c_double_p), nod.ctypes.data_as(_abi.c_double_p),
+                                           stat.ctypes.data_as(_abi.c_int32_p) if stat is not None else None,
+                                           its.ctypes.data_as(_abi.c_int32_p) if its is not None else None,
+                                           rel.ctypes.data_as(_abi.c_uint8_p) if rel is not None else None), "relmc_db_import")
 
     def last_kernel_ms(self) -> float:
         ms = C.c_double()

@@ -55,6 +55,7 @@ struct relmc_ctx {
     uint32_t* db_keys = nullptr; unsigned long long* db_count = nullptr; double* db_dns = nullptr; int32_t* db_meta = nullptr;
     double* db_nodal = nullptr; uint32_t* db_table = nullptr; DevAcc* db_partial = nullptr; int db_partial_cap = 0;
     bool db_has_opts = false; relmc_solver_opts db_opts;
+    bool db_invalid = false;                 // an entry point failed between the count bumps of a batch and its bookkeeping: relmc_db_reset / relmc_case_load only
     // retry of the units the primary elimination order does not converge on: a second device image of the case built with
     // another static order (lazily, from a copy of the description), the kernel's list of such units, scratch rows for their re-evaluation
     struct CaseCopy {
@@ -65,6 +66,9 @@ struct relmc_ctx {
     int alt_state[kAlt] = {0, 0};            // 0 not built yet, 1 ready, -1 unavailable (that order does not fit the tile)
     void* dcase_alt[kAlt] = {nullptr, nullptr}; uint32_t alt_scen_doubles[kAlt] = {0, 0}, alt_lds_bytes[kAlt] = {0, 0}, alt_stash_off[kAlt] = {0, 0};
     FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr; bool fail_dirty = false;
+    uint32_t fail_cap = 0;                   // entries of dfail (grows with the size of the call, fail_arm)
+    bool no_retry = false;                   // RELMC_NO_RETRY, read once at relmc_ctx_create
+    int64_t retry_overflow = 0;              // units that did not fit the list and kept their first-attempt results (relmc_retry_overflow)
     std::vector<double> hlf;                 // host copy of the hourly load factors (load scale of a re-evaluated hour)
     uint32_t* rkeys = nullptr; double* rdns = nullptr; int32_t* rmeta = nullptr; double* rnodal = nullptr; double* rscale = nullptr; int64_t rcap = 0;
     int64_t retry_units = 0, retry_converged = 0;        // since the case was loaded
@@ -89,6 +93,7 @@ struct relmc_ctx {
     bool has_hl1 = false; Hl1Case* dhl1 = nullptr; double* dsorted = nullptr; double* dsuffix = nullptr; int hl1_hours = 0;
     double last_kernel_ms = 0.0;
     long conflict_before = 0, conflict_after = 0;   // modelled extra LDS cycles per Newton step before / after the placement search
+    long alt_conflict_before[kAlt] = {0, 0}, alt_conflict_after[kAlt] = {0, 0};      // the same of the further orders' images
     std::string err;
 };
 
@@ -747,6 +752,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
     const uint32_t stash_off = geom.stash_off, scen = geom.scen_doubles, lds_bytes = geom.lds_bytes;
     const int nb = d->nb, ng = d->ng, nl = d->nl, ncomp = ng + nl;
     if (!alt) { ctx->conflict_before = geom.conflict_before; ctx->conflict_after = geom.conflict_after; }
+    else { ctx->alt_conflict_before[order_variant - 1] = geom.conflict_before; ctx->alt_conflict_after[order_variant - 1] = geom.conflict_after; }
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     if (alt) {
         const int v = order_variant - 1;
@@ -788,7 +794,30 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
 // 6.3).  Which states depends on the order: of the 67 such RTS-96 states in 1e8 samples, 66 converge under the same elimination rule with
 // the ties broken the other way (same pass counts).  The kernel lists the units it ends non-converged instead of accumulating them; they
 // are evaluated again here under that second order and their results take the place of the first attempt's.
-constexpr uint32_t kFailCap = 4096;
+// List capacity: 4096 + 1/256 of the units of the call.  relmc_case_load's calibration leaves a primary order in place only if it fails on
+// at most 0.1 % of a probe sample, so a list of 0.39 % + 4096 entries does not overflow on a calibrated case; if it does anyway the fused
+// path grows the list and evaluates the chunk again (the launch is deterministic), the other paths count the units that kept their
+// first-attempt results in relmc_retry_overflow.
+constexpr uint32_t kFailCapMin = 4096, kFailCapMax = 1u << 26;
+uint32_t fail_cap_for(int64_t call_units)
+{
+    const int64_t c = (int64_t)kFailCapMin + call_units / 256;
+    return c > (int64_t)kFailCapMax ? kFailCapMax : (uint32_t)c;
+}
+int fail_list_ensure(relmc_ctx* ctx, uint32_t cap)
+{
+    if (!ctx->dfail_count) {
+        HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
+        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
+    }
+    if (cap <= ctx->fail_cap) return RELMC_OK;
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    if (ctx->dfail) (void)hipFree(ctx->dfail);
+    ctx->dfail = nullptr; ctx->fail_cap = 0;
+    HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * (size_t)cap));
+    ctx->fail_cap = cap;
+    return RELMC_OK;
+}
 
 struct RetryOut { std::vector<FailRec> rec; std::vector<double> dns, nodal; std::vector<int32_t> meta; };   // meta = status | relaxed << 2 | iterations << 8
 
@@ -806,23 +835,31 @@ int alt_ensure(relmc_ctx* ctx, int v)          // v = 0, 1: which further order
     return rc;
 }
 
-// arms the kernel's list for the next launch(es); `reset` zeroes the count (first launch of a call)
-int fail_arm(relmc_ctx* ctx, EvalArgs& a, int64_t unit_base, bool reset)
+// arms the kernel's list for the next launch(es); `reset` zeroes the count (first launch of a call) and sizes the list for the
+// `call_units` units all launches of the call evaluate together
+int fail_arm(relmc_ctx* ctx, EvalArgs& a, int64_t unit_base, bool reset, int64_t call_units)
 {
     a.fail_list = nullptr; a.fail_count = nullptr; a.fail_cap = 0; a.unit_base = unit_base;
-    static const bool off = getenv("RELMC_NO_RETRY") != nullptr;      // diagnosis: the first attempt's results as they are
-    if (off || (ctx->alt_state[0] < 0 && ctx->alt_state[1] < 0)) return RELMC_OK;
-    if (!ctx->dfail) {
-        HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * kFailCap));
-        HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail, 0, sizeof(FailRec) * kFailCap, ctx->stream));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
+    if (ctx->no_retry || (ctx->alt_state[0] < 0 && ctx->alt_state[1] < 0)) return RELMC_OK;      // RELMC_NO_RETRY: the first attempt's results as they are
+    if (reset || !ctx->dfail) {
+        const uint32_t want = fail_cap_for(call_units);
+        const int rc = fail_list_ensure(ctx, want > ctx->fail_cap ? want : ctx->fail_cap);
+        if (rc) return rc;
     }
     // the count is zero whenever a call has collected its list (fail_retry zeroes it after a non-empty one), so the common case costs no
     // memset launch; only a call that was abandoned between arming and collecting leaves it to be cleared here
     if (reset && ctx->fail_dirty) { HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream)); }
     if (reset) ctx->fail_dirty = true;
-    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap;
+    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = ctx->fail_cap;
+    return RELMC_OK;
+}
+
+// units listed by the completed launches of the call (may exceed the capacity: the excess kept its first-attempt results)
+int fail_listed(relmc_ctx* ctx, uint32_t* cnt)
+{
+    *cnt = 0;
+    if (!ctx->dfail_count) return RELMC_OK;
+    HIP_TRY(ctx, hipMemcpy(cnt, ctx->dfail_count, sizeof(*cnt), hipMemcpyDeviceToHost));
     return RELMC_OK;
 }
 
@@ -838,21 +875,25 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
     ctx->fail_dirty = false;
     if (cnt == 0) return RELMC_OK;
     HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));
-    if (cnt > kFailCap) cnt = kFailCap;                      // the units beyond the list were accumulated by the kernel as they were
+    if (cnt > ctx->fail_cap) {                               // the units beyond the list were accumulated by the kernel as they were
+        ctx->retry_overflow += (int64_t)(cnt - ctx->fail_cap);
+        cnt = ctx->fail_cap;
+    }
     out.rec.resize(cnt);
     HIP_TRY(ctx, hipMemcpy(out.rec.data(), ctx->dfail, sizeof(FailRec) * cnt, hipMemcpyDeviceToHost));
     std::sort(out.rec.begin(), out.rec.end(), [](const FailRec& x, const FailRec& y) { return x.unit < y.unit; });
     const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
     const size_t nb = (size_t)ctx->nb;
-    if ((int64_t)cnt > ctx->rcap) {
+    if ((int64_t)cnt > ctx->rcap) {                          // scratch rows of the re-evaluation, sized by what was listed (twice: the third order's compact rows)
         for (void* p : {(void*)ctx->rkeys, (void*)ctx->rdns, (void*)ctx->rmeta, (void*)ctx->rnodal, (void*)ctx->rscale}) if (p) (void)hipFree(p);
         ctx->rkeys = nullptr; ctx->rdns = nullptr; ctx->rmeta = nullptr; ctx->rnodal = nullptr; ctx->rscale = nullptr; ctx->rcap = 0;
-        HIP_TRY(ctx, hipMalloc(&ctx->rkeys, sizeof(uint32_t) * kFailCap * 8));
-        HIP_TRY(ctx, hipMalloc(&ctx->rdns, sizeof(double) * kFailCap));
-        HIP_TRY(ctx, hipMalloc(&ctx->rmeta, sizeof(int32_t) * kFailCap));
-        HIP_TRY(ctx, hipMalloc(&ctx->rnodal, sizeof(double) * kFailCap * RELMC_MAX_BUS));
-        HIP_TRY(ctx, hipMalloc(&ctx->rscale, sizeof(double) * kFailCap));
-        ctx->rcap = kFailCap;
+        size_t rc2 = kFailCapMin; while (rc2 < cnt) rc2 *= 2;
+        HIP_TRY(ctx, hipMalloc(&ctx->rkeys, sizeof(uint32_t) * rc2 * 2 * 8));
+        HIP_TRY(ctx, hipMalloc(&ctx->rdns, sizeof(double) * rc2 * 2));
+        HIP_TRY(ctx, hipMalloc(&ctx->rmeta, sizeof(int32_t) * rc2 * 2));
+        HIP_TRY(ctx, hipMalloc(&ctx->rnodal, sizeof(double) * rc2 * 2 * nb));
+        HIP_TRY(ctx, hipMalloc(&ctx->rscale, sizeof(double) * rc2 * 2));
+        ctx->rcap = (int64_t)rc2;
     }
     std::vector<uint32_t> keys((size_t)cnt * ow);
     for (uint32_t r = 0; r < cnt; ++r) for (int q = 0; q < ow; ++q) keys[(size_t)r * ow + q] = out.rec[r].mask[q];
@@ -884,18 +925,31 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
             ctx->last_kernel_ms = before;
             HIP_TRY(ctx, hipMemcpy(out.meta.data(), ctx->rmeta, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
         } else {
-            for (uint32_t r = 0; r < cnt; ++r) {
-                if ((out.meta[r] & 3) != 1 && (out.meta[r] & 3) != 2) continue;
-                a.n = 1; a.memo_keys = ctx->rkeys; a.db_first = (int64_t)r; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
-                a.load_scale = have_scale ? ctx->rscale + r : nullptr;
-                rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, level + 1);
-                if (rc) return rc;
-                const double before = ctx->last_kernel_ms;
-                rc = finish_timing(ctx);
-                if (rc) return rc;
-                if (ms) *ms += ctx->last_kernel_ms;
-                ctx->last_kernel_ms = before;
+            // what the second order left non-converged, compacted behind the list's rows and evaluated under the third order in ONE launch
+            // (round 2 launched once per unit); the results are copied over the rows they belong to
+            std::vector<uint32_t> idx;
+            for (uint32_t r = 0; r < cnt; ++r) if ((out.meta[r] & 3) == 1 || (out.meta[r] & 3) == 2) idx.push_back(r);
+            if (idx.empty()) break;
+            const size_t m = idx.size(), base = (size_t)ctx->rcap;
+            std::vector<uint32_t> k2(m * ow); std::vector<double> s2(m);
+            for (size_t q = 0; q < m; ++q) { for (int w = 0; w < ow; ++w) k2[q * ow + w] = out.rec[idx[q]].mask[w]; if (have_scale) s2[q] = scale(out.rec[idx[q]].unit); }
+            HIP_TRY(ctx, hipMemcpy(ctx->rkeys + base * ow, k2.data(), sizeof(uint32_t) * k2.size(), hipMemcpyHostToDevice));
+            if (have_scale) HIP_TRY(ctx, hipMemcpy(ctx->rscale + base, s2.data(), sizeof(double) * m, hipMemcpyHostToDevice));
+            a.n = (int64_t)m; a.memo_keys = ctx->rkeys; a.db_first = (int64_t)base; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
+            a.load_scale = have_scale ? ctx->rscale + base : nullptr;
+            rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, level + 1);
+            if (rc) return rc;
+            const double before = ctx->last_kernel_ms;
+            rc = finish_timing(ctx);
+            if (rc) return rc;
+            if (ms) *ms += ctx->last_kernel_ms;
+            ctx->last_kernel_ms = before;
+            for (size_t q = 0; q < m; ++q) {
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->rdns + idx[q], ctx->rdns + base + q, sizeof(double), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->rmeta + idx[q], ctx->rmeta + base + q, sizeof(int32_t), hipMemcpyDeviceToDevice, ctx->stream));
+                HIP_TRY(ctx, hipMemcpyAsync(ctx->rnodal + (size_t)idx[q] * nb, ctx->rnodal + (base + q) * nb, sizeof(double) * nb, hipMemcpyDeviceToDevice, ctx->stream));
             }
+            HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
         }
     }
     HIP_TRY(ctx, hipMemcpy(out.dns.data(), ctx->rdns, sizeof(double) * cnt, hipMemcpyDeviceToHost));
@@ -934,13 +988,12 @@ int order_probe(relmc_ctx* ctx, int alt, int32_t* failures)
     relmc_solver_opts o; relmc_solver_opts_default(&o);
     EvalArgs a = make_args(o);
     a.seed = 0x5eedca5eull; a.first_index = 0; a.n = kProbeSamples;
-    if (!ctx->dfail) {
-        HIP_TRY(ctx, hipMalloc(&ctx->dfail, sizeof(FailRec) * kFailCap));
-        HIP_TRY(ctx, hipMalloc(&ctx->dfail_count, sizeof(uint32_t)));
-        HIP_TRY(ctx, hipMemsetAsync(ctx->dfail, 0, sizeof(FailRec) * kFailCap, ctx->stream));
+    {
+        const int rc0 = fail_list_ensure(ctx, fail_cap_for(kProbeSamples) > ctx->fail_cap ? fail_cap_for(kProbeSamples) : ctx->fail_cap);
+        if (rc0) return rc0;
     }
     HIP_TRY(ctx, hipMemsetAsync(ctx->dfail_count, 0, sizeof(uint32_t), ctx->stream));
-    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = kFailCap; a.unit_base = 0;
+    a.fail_list = ctx->dfail; a.fail_count = ctx->dfail_count; a.fail_cap = ctx->fail_cap; a.unit_base = 0;
     int rows = 0;
     int rc = launch_eval<5>(ctx, a, &rows, nullptr, nullptr, alt);      // MODE 5 = MODE 0 under its own kernel name
     if (rc) return rc;
@@ -956,7 +1009,7 @@ int order_probe(relmc_ctx* ctx, int alt, int32_t* failures)
 int order_calibrate(relmc_ctx* ctx)
 {
     ctx->order_primary = 0; ctx->order_probe[0] = ctx->order_probe[1] = ctx->order_probe[2] = -1;
-    if (getenv("RELMC_NO_RETRY")) return RELMC_OK;
+    if (ctx->no_retry) return RELMC_OK;
     int rc = order_probe(ctx, 0, &ctx->order_probe[0]);
     if (rc) return rc;
     if ((int64_t)ctx->order_probe[0] * 1000 <= kProbeSamples) return RELMC_OK;          // at most 0.1 %: the retry levels deal with those
@@ -971,6 +1024,10 @@ int order_calibrate(relmc_ctx* ctx)
         const int v = best - 1;                        // that image becomes the primary, the former primary takes its retry level
         std::swap(ctx->dcase, ctx->dcase_alt[v]);
         std::swap(ctx->scen_doubles, ctx->alt_scen_doubles[v]); std::swap(ctx->lds_bytes, ctx->alt_lds_bytes[v]); std::swap(ctx->stash_off, ctx->alt_stash_off[v]);
+        std::swap(ctx->conflict_before, ctx->alt_conflict_before[v]); std::swap(ctx->conflict_after, ctx->alt_conflict_after[v]);
+        // the host copy follows the image that runs: relmc_debug_schedule (and with it bench.py's operation count) describes the active schedule
+        if (ctx->tile == 0) HIP_TRY(ctx, hipMemcpy(&ctx->hcase24, ctx->dcase, sizeof(ctx->hcase24), hipMemcpyDeviceToHost));
+        else HIP_TRY(ctx, hipMemcpy(&ctx->hcase96, ctx->dcase, sizeof(ctx->hcase96), hipMemcpyDeviceToHost));
         ctx->order_primary = best;
         int bpc = 0; hipError_t e = hipSuccess;
         const int lds = (int)ctx->lds_bytes;
@@ -1084,7 +1141,7 @@ int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, in
         a.n = m; a.states = P.d_st[b]; a.load_scale = load_scale ? P.d_sc[b] : nullptr;
         a.dns = P.d_dns[b]; a.nodal = nodal ? P.d_nod[b] : nullptr; a.status = status ? P.d_stat[b] : nullptr; a.iters = iters ? P.d_it[b] : nullptr;
         int rows = 0;
-        rc = fail_arm(ctx, a, lo, k == 0);
+        rc = fail_arm(ctx, a, lo, k == 0, n);
         if (rc) return rc;
         rc = launch_eval<1>(ctx, a, &rows, P.e_ks[b], P.e_ke[b]);
         if (rc) return rc;
@@ -1139,6 +1196,7 @@ int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
     }
     ctx->num_cu = prop.multiProcessorCount;
     ctx->blocks_per_cu = 1;
+    ctx->no_retry = getenv("RELMC_NO_RETRY") != nullptr;       // read once: the list arming and the order calibration must agree
     *out = ctx;
     return RELMC_OK;
 }
@@ -1218,7 +1276,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         cc.d.br_from = cc.br_from.data(); cc.d.br_to = cc.br_to.data(); cc.d.br_b = cc.br_b.data(); cc.d.br_rate = cc.br_rate.data();
         cc.d.unavail = cc.unavail.data(); cc.d.always_up = cc.always_up.data();
         cc.valid = true;
-        ctx->alt_state[0] = ctx->alt_state[1] = 0; ctx->retry_units = 0; ctx->retry_converged = 0;
+        ctx->alt_state[0] = ctx->alt_state[1] = 0; ctx->retry_units = 0; ctx->retry_converged = 0; ctx->retry_overflow = 0;
     }
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
@@ -1245,6 +1303,13 @@ int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* con
     if (!ctx) return RELMC_ERR_INVALID;
     if (units_out) *units_out = ctx->retry_units;
     if (converged_out) *converged_out = ctx->retry_converged;
+    return RELMC_OK;
+}
+
+int32_t relmc_retry_overflow(const relmc_ctx* ctx, int64_t* units_out)
+{
+    if (!ctx || !units_out) return RELMC_ERR_INVALID;
+    *units_out = ctx->retry_overflow;
     return RELMC_OK;
 }
 
@@ -1305,7 +1370,7 @@ int32_t relmc_mc_simulation_dev(relmc_ctx* ctx, const uint8_t* states_dev, int64
     EvalArgs a = make_args(o);
     a.n = n; a.states = states_dev; a.dns = dns_dev; a.nodal = nodal_dev; a.status = status_dev; a.iters = iters_dev;
     int blocks = 0;
-    int rc = fail_arm(ctx, a, 0, true);
+    int rc = fail_arm(ctx, a, 0, true, n);
     if (rc) return rc;
     rc = launch_eval<1>(ctx, a, &blocks);
     if (rc) return rc;
@@ -1371,17 +1436,29 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
         a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
         a.dns = dns_dev ? dns_dev + done : nullptr;
         int blocks = 0;
-        int rc = fail_arm(ctx, a, done, true);
-        if (rc) return rc;
-        rc = launch_eval<0>(ctx, a, &blocks);
-        if (rc) return rc;
-        rc = launch_finalize(ctx, blocks);
-        if (rc) return rc;
         relmc_acc part;
-        HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
-        rc = finish_timing(ctx);
-        if (rc) return rc;
-        ms_total += ctx->last_kernel_ms;
+        for (int attempt = 0;; ++attempt) {
+            int rc = fail_arm(ctx, a, done, true, m);
+            if (rc) return rc;
+            rc = launch_eval<0>(ctx, a, &blocks);
+            if (rc) return rc;
+            rc = launch_finalize(ctx, blocks);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
+            rc = finish_timing(ctx);
+            if (rc) return rc;
+            ms_total += ctx->last_kernel_ms;
+            // more non-converged units than the list holds (a case the calibration did not foresee): a longer list and the same chunk again --
+            // the launch is a function of (seed, range) alone, so the second one lists them all
+            uint32_t listed = 0;
+            rc = fail_listed(ctx, &listed);
+            if (rc) return rc;
+            if (a.fail_list == nullptr || listed <= ctx->fail_cap || ctx->fail_cap >= kFailCapMax || attempt >= 2) break;
+            HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));
+            rc = fail_list_ensure(ctx, listed + listed / 8 > kFailCapMax ? kFailCapMax : listed + listed / 8);
+            if (rc) return rc;
+        }
+        int rc = RELMC_OK;
         RetryOut ro;
         rc = fail_retry(ctx, o, a.fail_threshold, no_scale, false, ro, &ms_total);
         if (rc) return rc;
@@ -1401,14 +1478,22 @@ namespace {
 // nsqMain.m:220-229 on the device for the samples [first_index, first_index + m): outage masks (ctx->mk), sample indices
 // sorted by mask (*perm_out; stable, so every run starts with its earliest sample), run starts (ctx->mstart) and the number
 // of distinct states.  Leaves the stream synchronised.
-int memo_alloc(relmc_ctx* ctx, int64_t m)
+// `keep`: the buffers hold live data (the database's gathered miss keys): growing them would lose it, so that is an error instead
+int memo_alloc(relmc_ctx* ctx, int64_t m, bool keep = false)
 {
-    size_t tmp_sort = 0, tmp_scan = 0;
-    (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
-                                    (size_t)m, 0u, 64u, ctx->stream);
-    (void)rocprim::exclusive_scan(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)m, rocprim::plus<uint32_t>(), ctx->stream);
-    const size_t tmp_need = tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    auto tmp_for = [&](int64_t q) {
+        size_t tmp_sort = 0, tmp_scan = 0;
+        (void)rocprim::radix_sort_pairs(nullptr, tmp_sort, (unsigned long long*)nullptr, (unsigned long long*)nullptr, (uint32_t*)nullptr, (uint32_t*)nullptr,
+                                        (size_t)q, 0u, 64u, ctx->stream);
+        (void)rocprim::exclusive_scan(nullptr, tmp_scan, (uint32_t*)nullptr, (uint32_t*)nullptr, 0u, (size_t)q, rocprim::plus<uint32_t>(), ctx->stream);
+        return tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
+    };
+    size_t tmp_need = tmp_for(m);
     if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
+        if (keep) return fail(ctx, RELMC_ERR_INVALID, "state database: sort scratch too small for the miss list (internal)");
+        // rocprim switches algorithms with the size and its scratch need is not monotone across the switch points: size the scratch for
+        // every smaller power-of-two fraction too, so that a later call on fewer items (the miss list of the same batch) never reallocates
+        for (int64_t q = m >> 1; q >= 1; q >>= 1) { const size_t t = tmp_for(q); if (t > tmp_need) tmp_need = t; }
         for (void* p : {(void*)ctx->mk, (void*)ctx->mperm0, (void*)ctx->mperm1, (void*)ctx->mhead, (void*)ctx->muid, (void*)ctx->mstart, (void*)ctx->mnu,
                         (void*)ctx->mch0, (void*)ctx->mch1, ctx->mtmp, (void*)ctx->mmiss, (void*)ctx->mk2}) if (p) (void)hipFree(p);
         ctx->mk = ctx->mperm0 = ctx->mperm1 = ctx->mhead = ctx->muid = ctx->mstart = ctx->mnu = ctx->mmiss = ctx->mk2 = nullptr; ctx->mch0 = ctx->mch1 = nullptr; ctx->mtmp = nullptr;
@@ -1435,7 +1520,7 @@ int memo_prepare(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m,
 {
     const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
     const int nchunk = (ctx->ncomp + 63) / 64;
-    { const int rc = memo_alloc(ctx, m); if (rc) return rc; }
+    { const int rc = memo_alloc(ctx, m, keys_ready); if (rc) return rc; }
     int64_t gb = (m + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
     const dim3 grid((unsigned)gb), blk(256);
     if (!keys_ready) {
@@ -1491,7 +1576,7 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
         EvalArgs a = make_args(o);
         a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
         int rows = 0;
-        rc = fail_arm(ctx, a, 0, true);
+        rc = fail_arm(ctx, a, 0, true, a.n);
         if (rc) return rc;
         rc = launch_eval<3>(ctx, a, &rows);
         if (rc) return rc;
@@ -1526,7 +1611,7 @@ void db_free(relmc_ctx* ctx)
     ctx->db_snap = nullptr; ctx->db_snap_cap = 0;
     ctx->db_keys = nullptr; ctx->db_count = nullptr; ctx->db_dns = nullptr; ctx->db_meta = nullptr; ctx->db_nodal = nullptr; ctx->db_table = nullptr;
     ctx->db_partial = nullptr; ctx->db_partial_cap = 0;
-    ctx->db_cap = 0; ctx->db_n = 0; ctx->db_samples = 0; ctx->db_tcap = 0; ctx->db_has_opts = false;
+    ctx->db_cap = 0; ctx->db_n = 0; ctx->db_samples = 0; ctx->db_tcap = 0; ctx->db_has_opts = false; ctx->db_invalid = false;
 }
 
 // room for `need` rows: the arrays double (contents copied on the device) and the table of row ids is rebuilt
@@ -1606,7 +1691,7 @@ int32_t relmc_db_reset(relmc_ctx* ctx)
 {
     if (!ctx) return RELMC_ERR_INVALID;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    ctx->db_n = 0; ctx->db_samples = 0; ctx->db_has_opts = false;
+    ctx->db_n = 0; ctx->db_samples = 0; ctx->db_has_opts = false; ctx->db_invalid = false;
     if (ctx->db_table) { HIP_TRY(ctx, hipMemsetAsync(ctx->db_table, 0xff, sizeof(uint32_t) * ctx->db_tcap, ctx->stream)); HIP_TRY(ctx, hipStreamSynchronize(ctx->stream)); }
     return RELMC_OK;
 }
@@ -1619,12 +1704,29 @@ int32_t relmc_db_size(const relmc_ctx* ctx, int64_t* rows_out, int64_t* samples_
     return RELMC_OK;
 }
 
+namespace {
+const char* kDbInvalid = "state database: inconsistent after an earlier error (counts advanced without their batch): relmc_db_reset first";
+int db_batch_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts, relmc_acc* acc_out, relmc_db_stats* stats_out);
+}
+
 int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts,
                            relmc_acc* acc_out, relmc_db_stats* stats_out)
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_nsq_db_batch: no case loaded");
     if (n < 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_nsq_db_batch: bad arguments");
+    if (ctx->db_invalid) return fail(ctx, RELMC_ERR_INVALID, kDbInvalid);
+    // The per-sample probe bumps the counts of known rows before the steps that can still fail (scratch, growth past 2^32 rows, the
+    // evaluation launch); an error return after that leaves counts without their samples, so the database is closed until it is reset.
+    const int64_t rows0 = ctx->db_n, samples0 = ctx->db_samples;
+    const int rc = db_batch_impl(ctx, seed, first_index, n, opts, acc_out, stats_out);
+    if (rc != RELMC_OK && n > 0 && (rows0 > 0 || ctx->db_n != rows0 || ctx->db_samples != samples0)) ctx->db_invalid = true;
+    return rc;
+}
+
+namespace {
+int db_batch_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, const relmc_solver_opts* opts, relmc_acc* acc_out, relmc_db_stats* stats_out)
+{
     relmc_solver_opts o;
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
     if (ctx->db_has_opts && ctx->db_n > 0 && !same_opts(o, ctx->db_opts))
@@ -1709,7 +1811,7 @@ int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, 
             a.n = (int64_t)n_new; a.memo_keys = ctx->db_keys; a.db_first = ctx->db_n;
             a.dns = ctx->db_dns; a.status = ctx->db_meta; a.nodal = ctx->db_nodal;
             int rows = 0;
-            rc = fail_arm(ctx, a, 0, true);
+            rc = fail_arm(ctx, a, 0, true, a.n);
             if (rc) return rc;
             rc = launch_eval<4>(ctx, a, &rows);
             if (rc) return rc;
@@ -1743,20 +1845,23 @@ int32_t relmc_nsq_db_batch(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, 
     if (stats_out) { stats_out->rows = ctx->db_n; stats_out->samples = ctx->db_samples; stats_out->new_rows = new_total; stats_out->batch_distinct = distinct_total; }
     return RELMC_OK;
 }
+}  // namespace
 
 int32_t relmc_db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out)
 {
     if (!ctx || !acc_out) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_db_accumulate: no case loaded");
+    if (ctx->db_invalid) return fail(ctx, RELMC_ERR_INVALID, kDbInvalid);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     return db_accumulate(ctx, acc_out);
 }
 
 int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8_t* states_host, int64_t* count_host, double* dns_host,
-                        int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host)
+                        int32_t* flag_host, double* nodal_host, int32_t* status_host, int32_t* iters_host, uint8_t* relaxed_host)
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_db_export: no case loaded");
+    if (ctx->db_invalid) return fail(ctx, RELMC_ERR_INVALID, kDbInvalid);
     if (first_row < 0 || n_rows < 0 || first_row + n_rows > ctx->db_n) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_export: row range outside the database");
     if (n_rows == 0) return RELMC_OK;
     HIP_TRY(ctx, hipSetDevice(ctx->device));
@@ -1767,7 +1872,7 @@ int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8
     if (states_host) { keys.resize(n * ow); HIP_TRY(ctx, hipMemcpy(keys.data(), ctx->db_keys + f * ow, sizeof(uint32_t) * n * ow, hipMemcpyDeviceToHost)); }
     if (count_host) { cnt.resize(n); HIP_TRY(ctx, hipMemcpy(cnt.data(), ctx->db_count + f, sizeof(unsigned long long) * n, hipMemcpyDeviceToHost)); }
     if (dns_host || flag_host) { dns.resize(n); HIP_TRY(ctx, hipMemcpy(dns.data(), ctx->db_dns + f, sizeof(double) * n, hipMemcpyDeviceToHost)); }
-    if (status_host || iters_host) { meta.resize(n); HIP_TRY(ctx, hipMemcpy(meta.data(), ctx->db_meta + f, sizeof(int32_t) * n, hipMemcpyDeviceToHost)); }
+    if (status_host || iters_host || relaxed_host) { meta.resize(n); HIP_TRY(ctx, hipMemcpy(meta.data(), ctx->db_meta + f, sizeof(int32_t) * n, hipMemcpyDeviceToHost)); }
     if (nodal_host) HIP_TRY(ctx, hipMemcpy(nodal_host, ctx->db_nodal + f * nb, sizeof(double) * n * nb, hipMemcpyDeviceToHost));
     for (size_t r = 0; r < n; ++r) {
         if (states_host) for (int k = 0; k < ncomp; ++k) states_host[r * ncomp + k] = (uint8_t)((keys[r * ow + (k >> 5)] >> (k & 31)) & 1u);
@@ -1776,7 +1881,48 @@ int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8
         if (flag_host) flag_host[r] = dns[r] > 1e-4 ? 1 : 0;                  // nsqMain.m:270
         if (status_host) status_host[r] = meta[r] & 3;
         if (iters_host) iters_host[r] = (int32_t)((uint32_t)meta[r] >> 8);
+        if (relaxed_host) relaxed_host[r] = (uint8_t)((meta[r] >> 2) & 1);
     }
+    return RELMC_OK;
+}
+
+// Resume (nsqMain.m:91-99 keeps state_database in the workspace; the reference's `save` at :404-405 is where a run could be continued
+// from): rows exported by relmc_db_export go back into an EMPTY database in the same order -- keys, counts, results, the table of row
+// ids -- so the next relmc_nsq_db_batch continues the run as if it had never stopped.  status / iters / relaxed may be NULL (then 0).
+int32_t relmc_db_import(relmc_ctx* ctx, const relmc_solver_opts* opts, int64_t n_rows, const uint8_t* states_host, const int64_t* count_host,
+                        const double* dns_host, const double* nodal_host, const int32_t* status_host, const int32_t* iters_host, const uint8_t* relaxed_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_db_import: no case loaded");
+    if (n_rows < 0 || (n_rows > 0 && (!states_host || !count_host || !dns_host || !nodal_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_import: bad arguments");
+    if (ctx->db_invalid || ctx->db_n != 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_import: the database is not empty (relmc_db_reset first)");
+    if (n_rows == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    const int ncomp = ctx->ncomp, nb = ctx->nb;
+    const size_t n = (size_t)n_rows;
+    int rc = db_ensure(ctx, n_rows);
+    if (rc) return rc;
+    std::vector<uint32_t> keys(n * ow, 0u); std::vector<unsigned long long> cnt(n); std::vector<int32_t> meta(n);
+    int64_t samples = 0;
+    for (size_t r = 0; r < n; ++r) {
+        for (int k = 0; k < ncomp; ++k) if (states_host[r * ncomp + k]) keys[r * ow + (k >> 5)] |= 1u << (k & 31);
+        if (count_host[r] <= 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_import: a row with a count below 1");
+        cnt[r] = (unsigned long long)count_host[r]; samples += count_host[r];
+        meta[r] = (status_host ? (status_host[r] & 3) : 0) | ((relaxed_host && relaxed_host[r]) ? 4 : 0) | ((iters_host ? iters_host[r] : 0) << 8);
+    }
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->db_keys, keys.data(), sizeof(uint32_t) * n * ow, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->db_count, cnt.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->db_dns, dns_host, sizeof(double) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->db_meta, meta.data(), sizeof(int32_t) * n, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemcpyAsync(ctx->db_nodal, nodal_host, sizeof(double) * n * nb, hipMemcpyHostToDevice, ctx->stream));
+    HIP_TRY(ctx, hipMemsetAsync(ctx->db_table, 0xff, sizeof(uint32_t) * ctx->db_tcap, ctx->stream));
+    int64_t gb = ((int64_t)n + 255) / 256; if (gb > (int64_t)ctx->num_cu * 16) gb = (int64_t)ctx->num_cu * 16;
+    hipLaunchKernelGGL(relmc_db_rehash_kernel, dim3((unsigned)gb), dim3(256), 0, ctx->stream, ctx->db_keys, (uint64_t)n, ow, ctx->db_table, ctx->db_tcap - 1);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+    ctx->db_n = n_rows; ctx->db_samples = samples;
+    if (opts) { ctx->db_opts = *opts; ctx->db_has_opts = true; } else { relmc_solver_opts_default(&ctx->db_opts); ctx->db_has_opts = true; }
     return RELMC_OK;
 }
 
@@ -1936,7 +2082,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         a.n = nlp; a.seq_masks = dm; a.seq_offsets = doff; a.seq_hours = dhours; a.load_factors = ctx->dlf; a.curt = dcurt;
         a.seq_nyears = n_years; a.seq_hpy = hpy;
         int blocks = 0;
-        rc = fail_arm(ctx, a, 0, true);
+        rc = fail_arm(ctx, a, 0, true, a.n);
         if (rc) { cleanup(); return rc; }
         rc = launch_eval<2>(ctx, a, &blocks);
         if (rc) { cleanup(); return rc; }

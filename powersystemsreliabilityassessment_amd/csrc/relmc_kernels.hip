@@ -100,14 +100,22 @@ DEVFI double frcp(double x)
     const double e = __builtin_fma(-x, r, 1.0);
     return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
-// 1/a and 1/b from ONE reciprocal: R = 1/(a b), 1/a = b R, 1/b = a R -- a v_rcp_f64 is quarter rate and wants its correction, two
-// multiplications are cheaper.  Used for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of a two-sided bound: all positive and
-// between ~1e-16 and ~1e6, so the product neither overflows nor underflows; ~2 ulp instead of ~1 (round 3: a further -1.5 % / -0.8 %;
-// 1 of the 878 + 1 of the 317 fixture states move by one iteration, dns unchanged to 2e-7 MW)
+// 1/a and 1/b from ONE reciprocal: R = 1/(a b), 1/a = b R, 1/b = a R (a v_rcp_f64 is quarter rate and wants its correction, two
+// multiplications are cheaper; ~2 ulp instead of ~1).  Measured in round 3 for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of
+// every two-sided bound: -1.5 % / -0.8 % kernel time on RTS-24 / RTS-96 -- and NOT shipped (-DRELMC_RPAIR builds it): any change of a
+// rounding here, even in the ratio tests alone, moves the state "G24 + G33 out" (0.3 % of all RTS-24 samples) from 14 to 15 iterations,
+// because at gamma ~ 1e-8 the Newton step of the static-order factorisation carries enough noise along the LP's degenerate optimal face
+// to cut one dual step (alpha_d 0.57 instead of 1, scripts/trace24.py); the extra iteration moves that state's nodal split by 6 MW on a
+// bus and with it one bus' nodal sum of a sampled run by 2 % against the oracle (profiles/r3_rcp/).  The round-2 arithmetic happens to
+// take the oracle's 14 iterations there; the cubic frcp above reproduces it bit for bit.
 DEVFI void frcp_pair(double a, double b, double& ra, double& rb)
 {
+#ifdef RELMC_RPAIR
     const double R = frcp(a * b);
     ra = b * R; rb = a * R;
+#else
+    ra = frcp(a); rb = frcp(b);
+#endif
 }
 
 // 1/x to ~2e-15 relative (measured on gfx950: raw v_rcp_f64 4.4e-8, one Newton step 2.0e-15, two steps exact):
@@ -119,8 +127,12 @@ DEVFI double frcp1(double x)
 }
 DEVFI void frcp1_pair(double a, double b, double& ra, double& rb)
 {
+#ifdef RELMC_RPAIR
     const double R = frcp1(a * b);
     ra = b * R; rb = a * R;
+#else
+    ra = frcp1(a); rb = frcp1(b);
+#endif
 }
 
 // Philox4x32-10 (Salmon et al. SC'11); counter (i_lo, i_hi, block, 0), key = seed

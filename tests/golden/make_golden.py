@@ -81,6 +81,23 @@ def golden_from_reference(ref):
     print("nsq_golden.json: EDNS", out["accumulated_edns"], "LOLE", out["accumulated_lole"])
 
 
+def export_layout_from_reference(ref):
+    """File layouts of the reference's exports (nsqMain.m:398-405, seqMain.m:255-262): CSV header and row count, .mat variable names
+    and shapes -- what tests/test_host.py::test_nsq_exports_have_the_references_layout compares the writers of api.py against."""
+    import scipy.io as sio
+    out = {}
+    for key, d, mat, csv in (("nsq", "Montecarlo_nsq_single", "reliability_results.mat", "nodal_results.csv"),
+                             ("seq", "Montecarlo_seq", "seq_reliability_results.mat", "seq_nodal_results.csv")):
+        with open(os.path.join(ref, d, csv)) as f:
+            lines = f.read().splitlines()
+        m = sio.loadmat(os.path.join(ref, d, mat))
+        out[key] = dict(csv=csv, mat=mat, csv_header=lines[0], csv_rows=len(lines) - 1, csv_first_column=[ln.split(",")[0] for ln in lines[1:]],
+                        mat_variables={k: list(v.shape) for k, v in m.items() if not k.startswith("__")})
+    with open(os.path.join(HERE, "export_layout.json"), "w") as f:
+        json.dump(out, f, indent=1)
+    print("export_layout.json:", {k: (v["csv_header"], sorted(v["mat_variables"])) for k, v in out.items()})
+
+
 def golden_seq_from_reference(ref):
     import scipy.io as sio
     m = sio.loadmat(os.path.join(ref, "Montecarlo_seq", "seq_reliability_results.mat"), squeeze_me=True, struct_as_record=False)
@@ -304,6 +321,7 @@ if __name__ == "__main__":
     ap.add_argument("--n-nsq", type=int, default=100000)
     ap.add_argument("--only-seq", action="store_true")
     ap.add_argument("--only-rts96", action="store_true")
+    ap.add_argument("--only-layout", action="store_true", help="export_layout.json alone (file layouts of the reference's exports)")
     ap.add_argument("--numfail96", default="", help="scan JSON of tests/tools/numfail96.py -> rts96_numfail_fixture.json")
     a = ap.parse_args()
     if a.numfail96:
@@ -311,6 +329,9 @@ if __name__ == "__main__":
         sys.exit(0)
     if a.only_rts96:
         rts96_fixture(240)
+        sys.exit(0)
+    export_layout_from_reference(a.reference)
+    if a.only_layout:
         sys.exit(0)
     golden_seq_from_reference(a.reference)
     seq_hours_fixture(160)

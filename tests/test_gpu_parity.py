@@ -60,15 +60,19 @@ def test_mc_simulation_matches_oracle(engine, oracle, states_fixture, policy):
     np.testing.assert_allclose(dns, ref["dns"], rtol=0, atol=DNS_TOL)
     dit = np.abs(info["iters"] - ref["iters"])
     assert dit.max() <= 1 and (dit > 0).mean() < 0.01
-    # nodal: conservation is tight, the split only loosely (degenerate optimal face)
+    # nodal: conservation is tight; the split is a point of a degenerate optimal face (every virtual generator costs the same) that the
+    # iterate keeps drifting along, so a state that stops one iteration apart ends MWs away on single buses (measured round 3,
+    # tests/tools/nodal24_split.py: 6.1 MW on the one such state, at most 0.9 MW on the 877 others, 0.01 MW on average)
     shed = dns > 0
     np.testing.assert_allclose(nodal.sum(1)[shed], dns[shed], rtol=0, atol=2e-2)
     d = np.abs(nodal - ref["nodal"])
-    assert d.max() < 5.0 and d[shed].mean() < 0.05
+    same = dit == 0
+    assert d[same].max() < 1.5 and d[~same].max(initial=0.0) < 10.0 and d[shed].mean() < 0.02
+    assert np.quantile(d.max(1)[shed], 0.95) < 0.5
     assert np.all(nodal[~shed] == 0)
-    # aggregated over the fixture the split agrees closely
-    tot, tot_ref = nodal.sum(0), ref["nodal"].sum(0)
-    np.testing.assert_allclose(tot, tot_ref, rtol=2e-3, atol=1e-6)
+    # aggregated over the fixture the split agrees closely (2e-3 over the states with equal iteration counts, 5e-3 over all)
+    np.testing.assert_allclose(nodal[same].sum(0), ref["nodal"][same].sum(0), rtol=2e-3, atol=1e-6)
+    np.testing.assert_allclose(nodal.sum(0), ref["nodal"].sum(0), rtol=5e-3, atol=1e-6)
 
 
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
@@ -312,6 +316,25 @@ def test_fused_path_ragged_ranges(engine, oracle):
     assert engine.nsq_accumulate(21, 777, 0).n == 0
 
 
+def test_retry_list_overflow_is_rerun_not_dropped(engine, oracle):
+    """More non-converged units than the kernel's list holds (here: an iteration limit of 7 ends most samples at MAXIT): the fused path
+    grows the list and evaluates the chunk again, so EVERY such unit goes through the further elimination orders (round-2 advice:
+    beyond 4096 units the first-attempt results were kept and depended on the order of the atomics)."""
+    o = api.mpoption(api.REFERENCE_EMULATE); o.max_it = 7
+    n = 60000
+    u0, v0 = engine.retry_stats()[0], engine.retry_overflow()
+    acc = engine.nsq_accumulate(3, 100, n, o)
+    u1, v1 = engine.retry_stats()[0], engine.retry_overflow()
+    ref = oracle.nsq_accumulate(3, 100, n, api.REFERENCE_EMULATE, opts=o)
+    assert acc.n == n and acc.n_nonconverged == ref.n_nonconverged > 4096 + n // 256
+    assert u1 - u0 == acc.n_nonconverged and v1 == v0                    # all of them retried, none left with a first-attempt result
+    ai, ad = acc.to_arrays(); ri, rd = ref.to_arrays()
+    assert np.array_equal(ai[:6], ri[:6]) and np.array_equal(ai[6:], ri[6:])
+    np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-7)
+    again = engine.nsq_accumulate(3, 100, n, o)                          # a function of (seed, range) alone
+    assert np.array_equal(again.to_arrays()[0], ai) and again.sum_dns == acc.sum_dns
+
+
 # ---- the reference's persistent unique-state database on the device (nsqMain.m:91-99, 220-278) -------------------------
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
 def test_state_database_matches_oracle_database(engine, oracle, policy):
@@ -350,6 +373,39 @@ def test_state_database_matches_oracle_database(engine, oracle, policy):
     mi, md = memo.to_arrays()
     assert np.array_equal(ai[:5], mi[:5]) and np.array_equal(ai[6:], mi[6:])
     np.testing.assert_allclose(ad[:2], md[:2], rtol=1e-8)
+
+
+def test_state_database_resume_from_an_export(engine):
+    """Checkpoint / resume (the reference keeps state_database in the workspace, nsqMain.m:91-99): export -> reset ->
+    import -> next batch gives the rows, their order, their counts and the accumulators of the run that never stopped."""
+    seed, n1, n2 = 5, 30_000, 30_000
+    for policy in (api.REFERENCE_EMULATE, api.PHYSICAL):
+        o = api.mpoption(policy)
+        engine.db_reset()
+        acc1, _ = engine.nsq_db_batch(seed, 0, n1, o)
+        saved = engine.db_export()
+        acc_full, st_full = engine.nsq_db_batch(seed, n1, n2, o)
+        rows_full = engine.db_export()
+        engine.db_reset()
+        assert engine.db_size() == (0, 0)
+        engine.db_import(saved, o)
+        assert engine.db_size() == (len(saved["count"]), n1)
+        back = engine.db_export()
+        for k in saved:
+            assert np.array_equal(saved[k], back[k]), k
+        assert bytes(engine.db_accumulate()) == bytes(acc1)                 # the same sums in the same (row-count dependent) order
+        acc2, st2 = engine.nsq_db_batch(seed, n1, n2, o)
+        rows2 = engine.db_export()
+        assert (st2.rows, st2.samples, st2.new_rows) == (st_full.rows, st_full.samples, st_full.new_rows)
+        for k in rows_full:
+            assert np.array_equal(rows_full[k], rows2[k]), k
+        assert bytes(acc2) == bytes(acc_full)
+        with pytest.raises(api.RelmcError):                                 # only into an empty database
+            engine.db_import(saved, o)
+        with pytest.raises(api.RelmcError):                                 # rows of other solver options are refused by the next batch
+            o2 = api.mpoption(policy); o2.max_it = 30
+            engine.nsq_db_batch(seed, n1 + n2, 100, o2)
+    engine.db_reset()
 
 
 def test_state_database_batch_size_independent(engine):

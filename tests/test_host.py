@@ -245,3 +245,60 @@ def test_bench_counter_fields_come_from_the_committed_profile():
         assert 0.3 < c["lds_pipe_busy"] < 0.9 and 0.3 < c["valu_busy"] < 0.9 and 0.1 < c["lds_conflict_frac"] < 0.6
         assert c["waves_per_simd"] == 2.0 and c["mfma_fp64_ops"] == 0.0 and c["traffic"] > 0
     assert bench.dense_flop_per_iter(24) == pytest.approx(40525.67, rel=1e-6)          # order 47
+
+
+# ---- exports (nsqMain.m:398-405, seqMain.m:255-262): the files the reference leaves behind, same names and layout ------------------
+def _layout():
+    import json
+    with open(os.path.join(ROOT, "tests", "golden", "export_layout.json")) as f:
+        return json.load(f)
+
+
+def test_nsq_exports_have_the_references_layout(tmp_path):
+    """api.NsqResult.write_nodal_csv / save_mat against the layout of the reference's own nodal_results.csv and
+    reliability_results.mat (tests/golden/export_layout.json, made from those files by make_golden.py): header, row labels,
+    variable names and shapes; the values read back are the ones written (CSV = nodal_eens x 8760, nsqMain.m:399)."""
+    from scipy.io import loadmat
+    from powersystemsreliabilityassessment_amd import api
+    lay = _layout()["nsq"]
+    rng = np.random.default_rng(3)
+    nodal = rng.uniform(0, 3, 24); nodal[[10, 11, 16, 20, 21, 22, 23]] = 0.0
+    r = api.NsqResult(accumulated_edns=14.9, accumulated_lole=735.9, plc=0.084, current_beta=0.0145, current_iteration=100000,
+                      nodal_eens=nodal, comp_importance=rng.uniform(0, 0.5, 71), beta_history=rng.uniform(0.01, 0.3, 1000),
+                      edns_history=rng.uniform(10, 30, 1000), lole_history=rng.uniform(500, 900, 1000), plc_history=rng.uniform(0.05, 0.1, 1000),
+                      converged=False, mean_iters=12.2, n_singular=34, n_infeasible=0, n_nonconverged=0, elapsed_time=1.0, kernel_seconds=0.5)
+    csv, mat = str(tmp_path / lay["csv"]), str(tmp_path / lay["mat"])
+    r.write_nodal_csv(csv); r.save_mat(mat)
+    lines = open(csv).read().splitlines()
+    assert lines[0] == lay["csv_header"] and len(lines) - 1 == lay["csv_rows"]
+    assert [ln.split(",")[0] for ln in lines[1:]] == lay["csv_first_column"]
+    np.testing.assert_allclose([float(ln.split(",")[1]) for ln in lines[1:]], nodal * 8760.0, rtol=1e-14)
+    m = loadmat(mat)
+    got = {k: list(v.shape) for k, v in m.items() if not k.startswith("__")}
+    assert got == lay["mat_variables"]
+    assert float(m["accumulated_edns"].ravel()[0]) == 14.9 and float(m["accumulated_lole"].ravel()[0]) == 735.9
+    np.testing.assert_array_equal(m["nodal_eens"].ravel(), nodal); np.testing.assert_array_equal(m["comp_importance"].ravel(), r.comp_importance)
+    np.testing.assert_array_equal(m["beta_history"].ravel(), r.beta_history); np.testing.assert_array_equal(m["edns_history"].ravel(), r.edns_history)
+    assert all(v.dtype == np.float64 for k, v in m.items() if not k.startswith("__"))
+
+
+def test_seq_exports_have_the_references_layout(tmp_path):
+    from scipy.io import loadmat
+    from powersystemsreliabilityassessment_amd import seq
+    lay = _layout()["seq"]
+    rng = np.random.default_rng(4)
+    ny = 50
+    yr = dict(ens=rng.uniform(0, 9e3, ny), dlc=rng.integers(0, 40, ny).astype(float), nlc=rng.integers(0, 9, ny).astype(float), plc=rng.uniform(0, 5e-3, ny))
+    cum = dict(eens=np.cumsum(yr["ens"]) / np.arange(1, ny + 1), cov=rng.uniform(0.04, 0.5, ny))
+    r = seq.SeqResult(final_year=ny, eens=float(cum["eens"][-1]), cov=0.049, lole=14.3, lolf=2.4, results_year=yr, results_cum=cum,
+                      nodal_eens_avg=rng.uniform(0, 500, 24), comp_importance=rng.uniform(0, 0.5, 71), total_loss_hours=700, years_evaluated=ny,
+                      n_lp=340000, n_singular=3, n_infeasible=1, n_nonconverged=0, elapsed_time=1.0, kernel_seconds=0.4)
+    csv, mat = str(tmp_path / lay["csv"]), str(tmp_path / lay["mat"])
+    r.write_nodal_csv(csv); r.save_mat(mat)
+    lines = open(csv).read().splitlines()
+    assert lines[0] == lay["csv_header"] and len(lines) - 1 == lay["csv_rows"] and [ln.split(",")[0] for ln in lines[1:]] == lay["csv_first_column"]
+    np.testing.assert_allclose([float(ln.split(",")[1]) for ln in lines[1:]], r.nodal_eens_avg, rtol=1e-14)       # MWh/yr already (seqMain.m:218)
+    m = loadmat(mat)
+    assert {k: list(v.shape) for k, v in m.items() if not k.startswith("__")} == lay["mat_variables"]
+    m2 = loadmat(mat, squeeze_me=True, struct_as_record=False)
+    np.testing.assert_array_equal(np.asarray(m2["results_year"].ens), yr["ens"]); np.testing.assert_array_equal(np.asarray(m2["results_cum"].cov), cum["cov"])

@@ -114,19 +114,21 @@ def test_gpu96_states_parity(engine96, oracle96, fixture96):
 
 @pytest.mark.gpu
 def test_gpu96_accumulate_matches_oracle(engine96, oracle96):
-    n = 3000
+    n = 20000                                                     # ~ 290 shedding samples; the oracle takes ~ 25 s on the GPU box's cores
     acc = engine96.nsq_accumulate(7, 123456, n)
     ref = oracle96.nsq_accumulate(7, 123456, n, _abi.RELMC_REFERENCE_EMULATE)
     ai, ad = acc.to_arrays(); ri, rd = ref.to_arrays()
     np.testing.assert_array_equal(ai[:5], ri[:5])                 # n, n_fail, n_singular, n_infeasible, n_nonconverged
-    assert abs(int(ai[5]) - int(ri[5])) <= 3                      # sum of iterations (see test_gpu96_states_parity)
+    assert abs(int(ai[5]) - int(ri[5])) <= 20                     # sum of iterations (see test_gpu96_states_parity)
     np.testing.assert_array_equal(ai[6:], ri[6:])                 # component-down counts during loss
     np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8)         # sum dns, sum dns^2
-    # the split of a state's curtailment over the buses is not unique on this three-area network (the C oracle and
-    # the numpy restatement differ by tens of MW per bus on single states, tests/golden/rts96_states_fixture.json):
-    # the totals agree, the per-bus sums agree loosely
+    # Per-bus sums of the sampled run: 2 % (measured round 3: 0.84 %, 23 MW on the worst bus).  The split of a state's curtailment over
+    # the buses is a point of a degenerate optimal face; on the heavy-outage states of the fixtures (317 + 67 states, 112 GW shed in
+    # total) device and C oracle end tens of MW apart on single buses with totals equal to 5e-4 MW (tests/tools/nodal96_agg.py: per-bus
+    # sums over those states differ by 4 % in the median, 23 % at worst; the C oracle and the numpy restatement do the same to each
+    # other), which is why that set pins totals, not buses.
     assert ad[2:].sum() == pytest.approx(rd[2:].sum(), rel=1e-6)
-    np.testing.assert_allclose(ad[2:], rd[2:], rtol=0.25, atol=1.0)
+    np.testing.assert_allclose(ad[2:], rd[2:], rtol=2e-2, atol=1.0)
     assert acc.n == n and acc.n_nonconverged == 0
 
 
