@@ -52,8 +52,11 @@ def main():
                     help="nsq24 = BASELINE configs[1] (the headline, default); rts96 = configs[4] shape; seq = configs[3] shape")
     ap.add_argument("--years", type=int, default=125, help="seq workload: simulated years per GPU per step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--comm", choices=["torch", "native"], default="torch",
-                    help="who all-reduces relmc_acc: torch.distributed (default) or the library's own RCCL communicator (relmc_comm_*)")
+    ap.add_argument("--comm", choices=["torch", "native", "host"], default="torch",
+                    help="who all-reduces relmc_acc: torch.distributed (default); native = the library's own RCCL communicator (relmc_comm_*: the "
+                         "128-byte id travels over a gloo group, torch holds NO nccl group in the process); host = torch's collective registered "
+                         "with the library as the host transport (relmc_comm_set_host_allreduce).  native / host run the multi-rank nsqMain loop "
+                         "below the C ABI (relmc_nsq_run)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
@@ -79,15 +82,18 @@ def main():
         local_rank = 0
     torch.cuda.set_device(local_rank)
     device = torch.device("cuda", local_rank)
+    # --comm native: ONE RCCL user in the process (the library's communicator), so torch gets a gloo group for the rendezvous,
+    # the barriers and the max over ranks of the elapsed time
+    pg_backend = "gloo" if args.comm == "native" else args.backend
     if world > 1:
-        if args.backend == "nccl":
+        if pg_backend == "nccl":
             dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
         else:
-            dist.init_process_group(args.backend, rank=rank, world_size=world)
+            dist.init_process_group(pg_backend, rank=rank, world_size=world)
 
     def sync():
         if world > 1:
-            dist.barrier(device_ids=[local_rank]) if args.backend == "nccl" else dist.barrier()
+            dist.barrier(device_ids=[local_rank]) if pg_backend == "nccl" else dist.barrier()
         torch.cuda.synchronize()
 
     policy = api.REFERENCE_EMULATE if args.policy == "emulate" else api.PHYSICAL
@@ -99,11 +105,21 @@ def main():
         case = case24.rts24()
     eng = api.Engine(case, device=local_rank)
     comm = None
-    if world > 1 and args.comm == "native":
-        comm = rdist.NativeComm(eng, rank, world)           # RCCL through the C ABI; the unique id travels over the torch store
+    if world > 1 and args.comm != "torch":
+        try:
+            # native: RCCL through the C ABI, the unique id travels over the gloo group; host: torch's collective as the library's transport
+            comm = rdist.NativeComm(eng, rank, world) if args.comm == "native" else rdist.HostComm(eng, rank, world, device)
+        except api.RelmcError as e:
+            # no hang, no retry: every rank reports what RCCL said and leaves with a non-zero code
+            print(f"bench.py: rank {rank}: communicator init failed: {e}", file=sys.stderr, flush=True)
+            sys.exit(3)
+    ar_seconds, ar_calls = [0.0], [0]
 
     def allreduce(acc):
-        return comm.allreduce_acc(acc) if comm is not None else rdist.allreduce_acc(acc, device)
+        t_ = time.perf_counter()
+        out_ = comm.allreduce_acc(acc) if comm is not None else rdist.allreduce_acc(acc, device)
+        ar_seconds[0] += time.perf_counter() - t_; ar_calls[0] += 1
+        return out_
 
     B = args.batch
     if args.workload in ("nsq24", "rts96"):
@@ -149,21 +165,41 @@ def main():
         total = acc if total is None else rdist.merge(total, acc)
     sync()
     elapsed = time.perf_counter() - t0
+    kernel_ms_per_rank = [sum(kernel_ms) / len(kernel_ms)]
     if world > 1:
-        t = torch.tensor([elapsed], dtype=torch.float64, device=device if args.backend == "nccl" else "cpu")
+        t = torch.tensor([elapsed], dtype=torch.float64, device=device if pg_backend == "nccl" else "cpu")
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
+        box = [None] * world
+        dist.all_gather_object(box, kernel_ms_per_rank[0])
+        kernel_ms_per_rank = [float(x) for x in box]
+    # the collective as the run saw it: who carried it, how many ranks IT reports, what one all-reduce of relmc_acc cost
+    import ctypes as _C
+    from powersystemsreliabilityassessment_amd import _abi as _rabi
+    if comm is not None:
+        ci = comm.info()
+        comm_info = {"backend": comm.kind, "nranks_seen": ci["nranks_seen"], "allreduce_calls": ci["allreduce_calls"],
+                     "allreduce_us_avg": 1e6 * ci["allreduce_seconds"] / max(1, ci["allreduce_calls"])}
+    else:
+        comm_info = {"backend": ("torch-" + pg_backend) if world > 1 else "none", "nranks_seen": dist.get_world_size() if world > 1 else 1,
+                     "allreduce_calls": ar_calls[0] if world > 1 else 0, "allreduce_us_avg": (1e6 * ar_seconds[0] / max(1, ar_calls[0])) if world > 1 else 0.0}
+    comm_info["allreduce_bytes"] = _C.sizeof(_rabi.Acc)
+    if comm_info["nranks_seen"] != world:
+        print(f"bench.py: rank {rank}: the communicator reports {comm_info['nranks_seen']} ranks, the launcher {world}", file=sys.stderr, flush=True)
+        sys.exit(4)
 
     # wall-time to EENS CoV < 1 % over all ranks (second half of BASELINE.json's metric), outside the timed region
     ttc_multi = None
     if world > 1 and args.workload == "nsq24" and not args.no_time_to_cov:
         sync()
         t1 = time.perf_counter()
+        # with a communicator in the context the loop runs below the C ABI (relmc_nsq_run shards and all-reduces); otherwise in Python
         idx, tot, hist = rdist.nsq_run_distributed(lambda s, lo, n: eng.nsq_accumulate(s, lo, n, opts), case.nb, case.ncomp, seed=args.seed,
                                                    beta_limit=0.01, max_samples=50_000_000, batch=100_000 * world, device=device,
-                                                   allreduce=allreduce)
+                                                   allreduce=allreduce, engine=eng if comm is not None else None, mpopt=opts)
         sync()
-        ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": 100_000 * world}
+        ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": 100_000 * world,
+                     "loop": "relmc_nsq_run (below the C ABI)" if comm is not None else "dist.nsq_run_distributed (Python)"}
 
     if rank == 0:
         n_total = int(total.n)
@@ -190,8 +226,9 @@ def main():
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "policy": args.policy, "seed": args.seed,
                        "parallelism": f"scenario-index{' / year' if args.workload == 'seq' else ''} sharding x{world}, 1 all-reduce of relmc_acc per step "
-                                      f"({'RCCL through the C ABI' if comm is not None else 'torch.distributed ' + (args.backend if world > 1 else '(single rank: no collective)')})"},
+                                      f"({comm.kind + ' through the C ABI' if comm is not None else 'torch.distributed ' + (pg_backend if world > 1 else '(single rank: no collective)')})"},
             "roofline": roof,
+            "comm": comm_info, "kernel_ms_per_rank": kernel_ms_per_rank,
             "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "plc": total.n_fail / n_total,
                         "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged),
                         "second_attempts_rank0": list(eng.retry_stats())},     # units re-evaluated under a further elimination order, converged

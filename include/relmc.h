@@ -255,6 +255,17 @@ int32_t relmc_comm_unique_id(uint8_t id_out[RELMC_COMM_ID_BYTES]);
 int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint8_t id[RELMC_COMM_ID_BYTES]);
 int32_t relmc_comm_allreduce_acc(relmc_ctx* ctx, relmc_acc* acc_inout);
 int32_t relmc_comm_destroy(relmc_ctx* ctx);
+/* A host that brings its own transport (MPI, Julia Distributed, torch.distributed over gloo) registers it instead of an RCCL
+ * communicator: fn(user, acc) leaves the sum over all ranks in *acc on every rank (0 = ok) and is called in the same order on every
+ * rank.  With either kind of communicator of more than one rank in the context, relmc_nsq_run IS the multi-rank loop: every batch of
+ * the global sample stream is split contiguously over the ranks, one all-reduce per batch, every rank returns the same result
+ * (nsqMain.m:208-318 around the parfor of :257-263); relmc_comm_allreduce_acc goes through the registered collective as well.
+ * relmc_comm_info: kind 0 = none, 1 = RCCL (ranks / rank as ncclCommCount / ncclCommUserRank report them), 2 = host collective;
+ * all-reduces of relmc_acc issued through this context and the wall time spent in them.  Any output may be NULL. */
+typedef int32_t (*relmc_allreduce_fn)(void* user, relmc_acc* acc_inout);
+int32_t relmc_comm_set_host_allreduce(relmc_ctx* ctx, int32_t nranks, int32_t rank, relmc_allreduce_fn fn, void* user);
+int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks_out, int32_t* rank_out, int64_t* calls_out,
+                        double* seconds_out);
 
 /* ---- estimators (host arithmetic, no device) ---------------------------------------- */
 void relmc_acc_zero(relmc_acc* acc);

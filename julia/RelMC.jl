@@ -235,62 +235,53 @@ function comm_allreduce!(eng::Engine, acc::Acc)
     return acc
 end
 comm_destroy(eng::Engine) = ccall((:relmc_comm_destroy, LIB), Int32, (Ptr{Cvoid},), eng.h)
+"The host's own transport instead of RCCL: `fn = @cfunction(f, Int32, (Ptr{Cvoid}, Ptr{Acc}))` must leave the sum over all ranks in the
+accumulators it is handed (0 = ok), e.g. MPI.Allreduce! on the two halves of the struct (relmc_comm_set_host_allreduce)."
+comm_set_host_allreduce(eng::Engine, nranks::Integer, rank::Integer, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL) =
+    check(ccall((:relmc_comm_set_host_allreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}), eng.h, nranks, rank, fn, user),
+          eng.h, "relmc_comm_set_host_allreduce")
+"(kind 0 none / 1 RCCL / 2 host, ranks, this rank, all-reduces issued, seconds in them) as the communicator itself reports (relmc_comm_info)"
+function comm_info(eng::Engine)
+    kind = Ref{Int32}(0); n = Ref{Int32}(0); r = Ref{Int32}(0); calls = Ref{Int64}(0); sec = Ref{Cdouble}(0.0)
+    check(ccall((:relmc_comm_info, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ref{Int32}, Ref{Int32}, Ref{Int64}, Ref{Cdouble}), eng.h, kind, n, r, calls, sec),
+          eng.h, "relmc_comm_info")
+    return (kind=kind[], nranks=n[], rank=r[], allreduces=calls[], seconds=sec[])
+end
 
 "nsqMain: `while beta > beta_limit && n < max_iterations` (nsqMain.m:208-318) + post-processing (:345-393).
 distinct_states: false = every sample solved; true = distinct states of each batch solved once; :database = the reference's
-persistent unique-state database across batches.  rank / nranks: scenario-index sharding of every batch over the ranks of a
-communicator set up with comm_init (all-reduce per check).  verbose: the reference's console output."
+persistent unique-state database across batches.  More than one rank: give the engine a communicator first (comm_init = RCCL, or
+comm_set_host_allreduce = the host's own transport) and call nsqMain on EVERY rank -- the library splits every batch over the
+ranks, all-reduces once per batch and hands every rank the same result (relmc_nsq_run); there is no loop on the Julia side.
+verbose: the reference's console output."
 function nsqMain(eng::Engine; beta_limit=0.0017, max_iterations=100_000, samples_per_batch=100, seed=1, mpopt=mpoption(),
-                 distinct_states=false, rank=0, nranks=1, verbose=false)
+                 distinct_states=false, verbose=false)
     total = Acc(); ccall((:relmc_acc_zero, LIB), Cvoid, (Ref{Acc},), total)
-    done = 0; beta = Inf; idx = Indices(); rows = 0
-    beta_history = Float64[]; edns_history = Float64[]; lole_history = Float64[]; plc_history = Float64[]
+    idx = Indices(); rows = 0
     t0 = time()
-    if nranks == 1
-        # one rank: the loop runs inside the library (relmc_nsq_run), which evaluates small batches such as the reference's
-        # 100 many checkpoints per launch (DESIGN.md 6.8); histories and stopping point are those of the loop below
-        ncp = cld(max_iterations, samples_per_batch)
-        beta_history = zeros(ncp); edns_history = zeros(ncp); lole_history = zeros(ncp); plc_history = zeros(ncp)
-        mode = distinct_states === :database ? 2 : (distinct_states === true ? 1 : 0)
-        buf = zeros(UInt8, NSQ_RESULT_BYTES)
-        GC.@preserve beta_history edns_history lole_history plc_history buf total idx begin
-            o = NsqOpts(beta_limit, max_iterations, samples_per_batch, seed, 8760.0, SolverOptsC(mpopt), ncp, pointer(beta_history),
-                        pointer(edns_history), pointer(lole_history), pointer(plc_history), mode)
-            check(ccall((:relmc_nsq_run, LIB), Int32, (Ptr{Cvoid}, Ref{NsqOpts}, Ptr{UInt8}), eng.h, Ref(o), buf), eng.h, "relmc_nsq_run")
-            unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(total)), pointer(buf), NSQ_RESULT_IDX)
-            unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(idx)), pointer(buf) + NSQ_RESULT_IDX, NSQ_RESULT_TAIL - NSQ_RESULT_IDX)
-            k = unsafe_load(Ptr{Int64}(pointer(buf) + NSQ_RESULT_TAIL))
-        end
-        resize!(beta_history, k); resize!(edns_history, k); resize!(lole_history, k); resize!(plc_history, k)
-        done = idx.n; beta = idx.beta
-        mode == 2 && (rows = db_size(eng)[1])
-        if verbose
-            for c in 1:k
-                n_c = min(c * samples_per_batch, done)
-                n_c % 1000 == 0 && println("Iteration ", lpad(n_c, 6), ": Beta = ", round(beta_history[c], digits=6), ", EDNS = ",
-                                           round(edns_history[c], digits=4), " MW, LOLE = ", round(lole_history[c], digits=4), " hr/yr")
-            end
-        end
+    # the loop runs inside the library (relmc_nsq_run), which also evaluates small batches such as the reference's 100 many checkpoints
+    # per launch (DESIGN.md 6.8) and shards the batches over the ranks of the engine's communicator
+    ncp = cld(max_iterations, samples_per_batch)
+    beta_history = zeros(ncp); edns_history = zeros(ncp); lole_history = zeros(ncp); plc_history = zeros(ncp)
+    mode = distinct_states === :database ? 2 : (distinct_states === true ? 1 : 0)
+    buf = zeros(UInt8, NSQ_RESULT_BYTES)
+    k = 0
+    GC.@preserve beta_history edns_history lole_history plc_history buf total idx begin
+        o = NsqOpts(beta_limit, max_iterations, samples_per_batch, seed, 8760.0, SolverOptsC(mpopt), ncp, pointer(beta_history),
+                    pointer(edns_history), pointer(lole_history), pointer(plc_history), mode)
+        check(ccall((:relmc_nsq_run, LIB), Int32, (Ptr{Cvoid}, Ref{NsqOpts}, Ptr{UInt8}), eng.h, Ref(o), buf), eng.h, "relmc_nsq_run")
+        unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(total)), pointer(buf), NSQ_RESULT_IDX)
+        unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(idx)), pointer(buf) + NSQ_RESULT_IDX, NSQ_RESULT_TAIL - NSQ_RESULT_IDX)
+        k = unsafe_load(Ptr{Int64}(pointer(buf) + NSQ_RESULT_TAIL))
     end
-    nranks > 1 && distinct_states === :database && db_reset(eng)
-    while nranks > 1 && beta > beta_limit && done < max_iterations
-        m = min(samples_per_batch, max_iterations - done)
-        lo = done + div(m * rank, nranks); cnt = done + div(m * (rank + 1), nranks) - lo       # contiguous slice of the batch
-        if distinct_states === :database
-            part, st = nsq_db_batch(eng, seed, lo, cnt, mpopt); rows = st.rows                 # cumulative accumulators of this rank's database
-            nranks > 1 && comm_allreduce!(eng, part)
-            total = part
-        else
-            part = distinct_states ? nsq_accumulate_distinct(eng, seed, lo, cnt, mpopt)[1] : nsq_accumulate(eng, seed, lo, cnt, mpopt)
-            nranks > 1 && comm_allreduce!(eng, part)
-            ccall((:relmc_acc_merge, LIB), Cvoid, (Ref{Acc}, Ref{Acc}), total, part)
-        end
-        done += m
-        idx = indices(eng, total); beta = idx.beta
-        push!(beta_history, idx.beta); push!(edns_history, idx.edns); push!(lole_history, idx.lole); push!(plc_history, idx.plc)
-        if verbose && done % 1000 == 0                                                            # nsqMain.m:314-317
-            println("Iteration ", lpad(done, 6), ": Beta = ", round(idx.beta, digits=6), ", EDNS = ", round(idx.edns, digits=4),
-                    " MW, LOLE = ", round(idx.lole, digits=4), " hr/yr")
+    resize!(beta_history, k); resize!(edns_history, k); resize!(lole_history, k); resize!(plc_history, k)
+    done = idx.n; beta = idx.beta
+    mode == 2 && (rows = db_size(eng)[1])
+    if verbose
+        for c in 1:k
+            n_c = min(c * samples_per_batch, done)
+            n_c % 1000 == 0 && println("Iteration ", lpad(n_c, 6), ": Beta = ", round(beta_history[c], digits=6), ", EDNS = ",
+                                       round(edns_history[c], digits=4), " MW, LOLE = ", round(lole_history[c], digits=4), " hr/yr")
         end
     end
     nb = eng.sys.nb; nc = eng.sys.ng + eng.sys.nl

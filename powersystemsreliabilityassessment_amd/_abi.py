@@ -76,6 +76,10 @@ class Acc(C.Structure):
         return cls.from_buffer_copy(ints.tobytes() + dbls.tobytes())
 
 
+# relmc_allreduce_fn: int32 fn(void* user, relmc_acc* acc_inout)
+ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(Acc))
+
+
 class Indices(C.Structure):
     _fields_ = [
         ("n", C.c_int64),

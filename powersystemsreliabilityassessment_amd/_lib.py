@@ -23,7 +23,7 @@ EXPORTS = [
     "relmc_mc_simulation", "relmc_mc_simulation_dev", "relmc_nsq_accumulate", "relmc_nsq_accumulate_distinct",
     "relmc_last_kernel_ms", "relmc_acc_zero", "relmc_acc_merge", "relmc_nsq_indices",
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
-    "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy",
+    "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy", "relmc_comm_set_host_allreduce", "relmc_comm_info",
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_case_order",
 ]
@@ -110,6 +110,10 @@ def load():
     L.relmc_comm_allreduce_acc.restype = C.c_int32
     L.relmc_comm_destroy.argtypes = [vp]
     L.relmc_comm_destroy.restype = C.c_int32
+    L.relmc_comm_set_host_allreduce.argtypes = [vp, C.c_int32, C.c_int32, _abi.ALLREDUCE_FN, C.c_void_p]
+    L.relmc_comm_set_host_allreduce.restype = C.c_int32
+    L.relmc_comm_info.argtypes = [vp, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int64_p, _abi.c_double_p]
+    L.relmc_comm_info.restype = C.c_int32
     L.relmc_db_reset.argtypes = [vp]
     L.relmc_db_reset.restype = C.c_int32
     L.relmc_nsq_db_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts), C.POINTER(_abi.Acc),

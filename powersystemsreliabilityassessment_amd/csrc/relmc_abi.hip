@@ -87,6 +87,8 @@ struct relmc_ctx {
     } pipe;
     // RCCL communicator over the ranks of a multi-GPU run (optional; relmc_comm_*)
     void* comm = nullptr; int comm_nranks = 0, comm_rank = -1;
+    relmc_allreduce_fn host_allreduce = nullptr; void* host_allreduce_user = nullptr;     // the host's own collective instead of RCCL (relmc_comm_set_host_allreduce)
+    int64_t comm_calls = 0; double comm_seconds = 0.0;                                     // all-reduces of relmc_acc through this context, wall time in them
     // sequential track
     bool has_seq = false; SeqCase hseq; SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
@@ -2193,6 +2195,37 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         }
         cp++;
     };
+    constexpr int64_t kStretch = 1 << 18, kStretchMaxBatch = 8192;
+    // More than one rank (relmc_comm_init / relmc_comm_set_host_allreduce): every batch [done, done + m) of the global sample stream is split
+    // contiguously over the ranks, each evaluates its slice, ONE all-reduce of the accumulators per batch (the convergence check), and every
+    // rank computes the same indices and stops at the same batch -- the parfor of nsqMain.m:257-263 with the loop around it, so that a C,
+    // Julia or MATLAB host calls this one function on every rank.  The sampler is keyed by (seed, global index): the integers of the result
+    // do not depend on the number of ranks, the fp64 sums only in their summation order.  The state database (distinct_states = 2) is per
+    // rank (each rank's rows are the states of ITS slices); its accumulators are cumulative, so they are all-reduced as they are.
+    const int nranks = (ctx->comm || ctx->host_allreduce) ? ctx->comm_nranks : 1;
+    if (nranks > 1) {
+        const int64_t R = nranks, r = ctx->comm_rank;
+        while (beta > o->beta_limit && done < o->max_samples) {
+            const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;
+            const int64_t lo = done + m * r / R, cnt = done + m * (r + 1) / R - lo;
+            relmc_acc part;
+            relmc_acc_zero(&part);
+            int rc = RELMC_OK;
+            if (o->distinct_states == 2) rc = relmc_nsq_db_batch(ctx, o->seed, (uint64_t)lo, cnt, &o->solver, &part, nullptr);      // cumulative over this rank's slices
+            else if (cnt > 0) rc = o->distinct_states ? relmc_nsq_accumulate_distinct(ctx, o->seed, (uint64_t)lo, cnt, &o->solver, &part, nullptr)
+                                                      : relmc_nsq_accumulate(ctx, o->seed, (uint64_t)lo, cnt, &o->solver, &part);
+            if (rc) return rc;
+            if (cnt > 0 || o->distinct_states == 2) kernel_ms += ctx->last_kernel_ms;
+            rc = relmc_comm_allreduce_acc(ctx, &part);
+            if (rc) return rc;
+            if (o->distinct_states == 2) res->acc = part; else relmc_acc_merge(&res->acc, &part);
+            done += m;
+            relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
+            beta = res->idx.beta;
+            checkpoint(res->idx);
+        }
+    }
+    else
     // Small batches (the reference's own is 100 samples, nsqMain.m:60) would make every checkpoint one launch of a nearly
     // empty grid.  They are evaluated many at a time instead: one pass returns the accumulators of the whole stretch and
     // the dns of each of its samples; the four indices of every checkpoint inside it (nsqMain.m:286-301 need only the dns
@@ -2201,7 +2234,6 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     // the stretch), so that the result is the one of the batch-by-batch loop.  Only for batches whose launch is overhead-bound (a launch
     // costs 0.2-0.4 ms whatever its size, i.e. as much as 1e4 scenarios), and with stretches that grow with the samples already drawn
     // (256 batches at first, then as many samples as the run holds, up to 2^18): what a cut throws away stays in proportion to the run.
-    constexpr int64_t kStretch = 1 << 18, kStretchMaxBatch = 8192;
     if ((o->distinct_states == 0 || o->distinct_states == 2) && o->batch <= kStretchMaxBatch &&
         !std::getenv("RELMC_NSQ_NO_STRETCH") /* diagnosis: one launch per batch */) {
         const bool use_db = o->distinct_states == 2;
@@ -2337,6 +2369,8 @@ struct RcclApi {
     int (*GroupStart)() = nullptr;
     int (*GroupEnd)() = nullptr;
     const char* (*GetErrorString)(int) = nullptr;
+    int (*CommCount)(void*, int*) = nullptr;
+    int (*CommUserRank)(void*, int*) = nullptr;
 };
 RcclApi g_rccl;
 const char* rccl_load()
@@ -2354,6 +2388,8 @@ const char* rccl_load()
     g_rccl.GroupStart = reinterpret_cast<int (*)()>(dlsym(g_rccl.h, "ncclGroupStart"));
     g_rccl.GroupEnd = reinterpret_cast<int (*)()>(dlsym(g_rccl.h, "ncclGroupEnd"));
     g_rccl.GetErrorString = reinterpret_cast<const char* (*)(int)>(dlsym(g_rccl.h, "ncclGetErrorString"));
+    g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(g_rccl.h, "ncclCommCount"));
+    g_rccl.CommUserRank = reinterpret_cast<int (*)(void*, int*)>(dlsym(g_rccl.h, "ncclCommUserRank"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
         g_rccl.h = nullptr;
         return "relmc_comm: librccl.so lacks the expected entry points";
@@ -2385,7 +2421,7 @@ int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!id || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_init: bad arguments");
-    if (ctx->comm) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_init: the context already has a communicator");
+    if (ctx->comm || ctx->host_allreduce) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_init: the context already has a communicator");
     if (const char* e = rccl_load()) return fail(ctx, RELMC_ERR_UNSUPPORTED, e);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     RcclUid u;
@@ -2393,7 +2429,36 @@ int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint
     void* comm = nullptr;
     const int rc = g_rccl.CommInitRank(&comm, nranks, u, rank);
     if (rc != 0) return rccl_fail(ctx, "ncclCommInitRank", rc);
-    ctx->comm = comm; ctx->comm_nranks = nranks; ctx->comm_rank = rank;
+    ctx->comm = comm; ctx->comm_nranks = nranks; ctx->comm_rank = rank; ctx->comm_calls = 0; ctx->comm_seconds = 0.0;
+    return RELMC_OK;
+}
+
+// The host's own collective in the place of RCCL (MPI, Julia Distributed, torch.distributed over gloo, ...): fn(user, acc) must leave the
+// sum over all ranks in *acc on every rank and is called in the same order on every rank.  Everything else -- the sharding of every
+// batch, the loop, the stopping rule -- is the library's (relmc_nsq_run), so a host supplies transport, not logic.
+int32_t relmc_comm_set_host_allreduce(relmc_ctx* ctx, int32_t nranks, int32_t rank, relmc_allreduce_fn fn, void* user)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!fn || nranks < 1 || rank < 0 || rank >= nranks) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_set_host_allreduce: bad arguments");
+    if (ctx->comm || ctx->host_allreduce) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_set_host_allreduce: the context already has a communicator");
+    ctx->host_allreduce = fn; ctx->host_allreduce_user = user; ctx->comm_nranks = nranks; ctx->comm_rank = rank; ctx->comm_calls = 0; ctx->comm_seconds = 0.0;
+    return RELMC_OK;
+}
+
+// what the communicator itself says: kind 0 none, 1 RCCL (ranks and rank from ncclCommCount / ncclCommUserRank), 2 host collective
+int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks_out, int32_t* rank_out, int64_t* calls_out, double* seconds_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    int kind = 0, n = 1, r = 0;
+    if (ctx->comm) {
+        kind = 1; n = ctx->comm_nranks; r = ctx->comm_rank;
+        if (g_rccl.CommCount && g_rccl.CommUserRank) { int c = 0, u = 0; if (g_rccl.CommCount(ctx->comm, &c) == 0 && g_rccl.CommUserRank(ctx->comm, &u) == 0) { n = c; r = u; } }
+    } else if (ctx->host_allreduce) { kind = 2; n = ctx->comm_nranks; r = ctx->comm_rank; }
+    if (kind_out) *kind_out = kind;
+    if (nranks_out) *nranks_out = n;
+    if (rank_out) *rank_out = r;
+    if (calls_out) *calls_out = ctx->comm_calls;
+    if (seconds_out) *seconds_out = ctx->comm_seconds;
     return RELMC_OK;
 }
 
@@ -2402,6 +2467,12 @@ int32_t relmc_comm_init(relmc_ctx* ctx, int32_t nranks, int32_t rank, const uint
 int32_t relmc_comm_allreduce_acc(relmc_ctx* ctx, relmc_acc* acc)
 {
     if (!ctx || !acc) return RELMC_ERR_INVALID;
+    const auto t0 = std::chrono::steady_clock::now();
+    struct Tick { relmc_ctx* c; std::chrono::steady_clock::time_point t; ~Tick() { c->comm_calls++; c->comm_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } tick{ctx, t0};
+    if (ctx->host_allreduce) {
+        const int32_t rc = ctx->host_allreduce(ctx->host_allreduce_user, acc);
+        return rc == 0 ? RELMC_OK : fail(ctx, RELMC_ERR_HIP, "relmc_comm_allreduce_acc: the host's all-reduce returned " + std::to_string(rc));
+    }
     if (!ctx->comm) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_allreduce_acc: relmc_comm_init has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dacc, acc, sizeof(*acc), hipMemcpyHostToDevice, ctx->stream));
@@ -2422,7 +2493,7 @@ int32_t relmc_comm_destroy(relmc_ctx* ctx)
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (ctx->comm && g_rccl.CommDestroy) { (void)hipSetDevice(ctx->device); (void)g_rccl.CommDestroy(ctx->comm); }
-    ctx->comm = nullptr; ctx->comm_nranks = 0; ctx->comm_rank = -1;
+    ctx->comm = nullptr; ctx->comm_nranks = 0; ctx->comm_rank = -1; ctx->host_allreduce = nullptr; ctx->host_allreduce_user = nullptr;
     return RELMC_OK;
 }
 

@@ -48,20 +48,38 @@ def allreduce_acc(acc: _abi.Acc, device=None) -> _abi.Acc:
     return _abi.Acc.from_arrays(np.array(tot, dtype=np.int64), out[2 * n:])
 
 
+def _broadcast_bytes(payload, rank: int, world: int, key: str = "relmc_comm_id"):
+    """128 bytes from rank 0 to everybody through whatever rendezvous the host already has: the default torch.distributed group if
+    there is one (any backend; gloo is enough), else a TCPStore on MASTER_ADDR / MASTER_PORT + 1.  No collective on the GPUs."""
+    import os
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        box = [payload]
+        dist.broadcast_object_list(box, src=0)
+        return box[0]
+    from datetime import timedelta
+    store = dist.TCPStore(os.environ.get("MASTER_ADDR", "127.0.0.1"), int(os.environ.get("MASTER_PORT", "29500")) + 1, world, rank == 0,
+                          timeout=timedelta(seconds=120))
+    if rank == 0:
+        store.set(key, payload)
+    return bytes(store.get(key))
+
+
 class NativeComm:
-    """The library's own RCCL communicator (relmc_comm_*, include/relmc.h): what a Julia / C host would use.  Only the
-    128-byte unique id is exchanged through the host framework (here: torch.distributed's object broadcast)."""
+    """The library's own RCCL communicator (relmc_comm_*, include/relmc.h): what a Julia / C host would use.  Only the 128-byte
+    unique id is exchanged through the host's rendezvous (`_broadcast_bytes`); the process needs no torch `nccl` group beside it
+    (bench.py --comm native initialises torch.distributed with gloo for exactly that reason: ONE RCCL user per process).
+    Raises api.RelmcError with RCCL's message if the communicator cannot be built (e.g. two ranks on one GPU: "invalid usage")."""
+
+    kind = "rccl-native"
 
     def __init__(self, engine, rank: int, world: int):
         import ctypes as C
-        import torch.distributed as dist
         self.eng, self.rank, self.world = engine, rank, world
         uid = (C.c_uint8 * 128)()
         if rank == 0:
             engine._check(engine.L.relmc_comm_unique_id(uid), "relmc_comm_unique_id")
-        box = [bytes(uid)]
-        dist.broadcast_object_list(box, src=0)
-        uid = (C.c_uint8 * 128).from_buffer_copy(box[0])
+        uid = (C.c_uint8 * 128).from_buffer_copy(_broadcast_bytes(bytes(uid), rank, world))
         engine._check(engine.L.relmc_comm_init(engine._h, world, rank, uid), "relmc_comm_init")
 
     def allreduce_acc(self, acc: _abi.Acc) -> _abi.Acc:
@@ -70,8 +88,43 @@ class NativeComm:
         self.eng._check(self.eng.L.relmc_comm_allreduce_acc(self.eng._h, C.byref(out)), "relmc_comm_allreduce_acc")
         return out
 
+    def info(self) -> dict:
+        return comm_info(self.eng)
+
     def close(self):
         self.eng.L.relmc_comm_destroy(self.eng._h)
+
+
+class HostComm(NativeComm):
+    """The host's own transport registered with the library (relmc_comm_set_host_allreduce): here torch.distributed's default group
+    (gloo on CPU tensors, or nccl = RCCL).  The multi-rank loop itself stays below the C ABI (relmc_nsq_run)."""
+
+    kind = "host-collective"
+
+    def __init__(self, engine, rank: int, world: int, device=None):
+        import ctypes as C
+        self.eng, self.rank, self.world = engine, rank, world
+
+        def _cb(_user, acc_p):
+            try:
+                red = allreduce_acc(_abi.Acc.from_buffer_copy(bytes(acc_p.contents)), device)
+                C.memmove(acc_p, C.byref(red), C.sizeof(_abi.Acc))
+                return 0
+            except Exception:      # never let an exception cross the C frame
+                import traceback
+                traceback.print_exc()
+                return 1
+        self._cb = _abi.ALLREDUCE_FN(_cb)          # kept alive as long as the communicator
+        engine._check(engine.L.relmc_comm_set_host_allreduce(engine._h, world, rank, self._cb, None), "relmc_comm_set_host_allreduce")
+
+
+def comm_info(engine) -> dict:
+    """relmc_comm_info: what the context's communicator itself reports."""
+    import ctypes as C
+    kind, n, r, calls, sec = C.c_int32(), C.c_int32(), C.c_int32(), C.c_int64(), C.c_double()
+    engine._check(engine.L.relmc_comm_info(engine._h, C.byref(kind), C.byref(n), C.byref(r), C.byref(calls), C.byref(sec)), "relmc_comm_info")
+    return dict(kind={0: "none", 1: "rccl", 2: "host"}[kind.value], nranks_seen=n.value, rank=r.value, allreduce_calls=calls.value,
+                allreduce_seconds=sec.value)
 
 
 def merge(a: _abi.Acc, b: _abi.Acc) -> _abi.Acc:
@@ -96,8 +149,13 @@ def indices_from_acc(acc: _abi.Acc, nb: int, ncomp: int, hours_per_year: float =
 
 def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, beta_limit: float = 0.0017,
                         max_samples: int = 100000, batch: int = 100, hours_per_year: float = 8760.0,
-                        rank: int | None = None, world: int | None = None, device=None, allreduce=None, cumulative: bool = False):
+                        rank: int | None = None, world: int | None = None, device=None, allreduce=None, cumulative: bool = False,
+                        engine=None, mpopt=None, distinct_states=False):
     """The nsqMain loop (nsqMain.m:208-318) over `world` ranks.
+
+    engine = an api.Engine that holds a communicator (NativeComm / HostComm): the call goes to relmc_nsq_run, which IS the multi-rank
+    loop (accumulate_fn is not used).  Without an engine the loop below runs in Python around accumulate_fn: the restatement the CPU
+    tests check the sharding arithmetic with (gloo, no GPU).
 
     accumulate_fn(seed, first_index, n) -> _abi.Acc evaluates a scenario range on THIS rank
     (Engine.nsq_accumulate in production).  Returns (indices dict, merged Acc, history list).
@@ -106,6 +164,14 @@ def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, be
     running total instead of an increment.
     """
     import torch.distributed as dist
+    if engine is not None:
+        # production: the loop is the library's (relmc_nsq_run shards every batch over the ranks of the engine's communicator and
+        # all-reduces once per batch); this function only hands the options over
+        r = engine.nsqMain(beta_limit=beta_limit, max_iterations=max_samples, samples_per_batch=batch, seed=seed, mpopt=mpopt,
+                           distinct_states=distinct_states)
+        idx = indices_from_acc(r.acc, nb, ncomp, hours_per_year)
+        done = [min((k + 1) * batch, r.current_iteration) for k in range(len(r.beta_history))]
+        return idx, r.acc, list(zip(done, r.beta_history, r.edns_history, r.lole_history, r.plc_history))
     if rank is None or world is None:
         if dist.is_available() and dist.is_initialized():
             rank, world = dist.get_rank(), dist.get_world_size()

@@ -7,6 +7,40 @@
 
 static void* rd(FILE* f, size_t bytes) { void* p = malloc(bytes); if (fread(p, 1, bytes, f) != bytes) { fprintf(stderr, "short read\n"); exit(2); } return p; }
 
+/* "Transport" of the two-rank test: rank 0's all-reduce adds what rank 1 would have sent.  Rank 1's slice of the CURRENT batch is
+ * evaluated here, on a second context, from the same (seed, batch, rank) arithmetic relmc_nsq_run documents. */
+typedef struct { relmc_ctx* other; const relmc_nsq_opts* o; int64_t done; int calls; } two_rank_t;
+static int32_t two_rank_allreduce(void* user, relmc_acc* acc)
+{
+    two_rank_t* t = (two_rank_t*)user;
+    const int64_t m = (t->o->max_samples - t->done) < t->o->batch ? (t->o->max_samples - t->done) : t->o->batch;
+    const int64_t lo = t->done + m * 1 / 2, cnt = t->done + m * 2 / 2 - lo;          /* rank 1 of 2 */
+    relmc_acc part;
+    if (relmc_nsq_accumulate(t->other, t->o->seed, (uint64_t)lo, cnt, &t->o->solver, &part) != RELMC_OK) return 1;
+    relmc_acc_merge(acc, &part);
+    t->done += m; t->calls++;
+    return 0;
+}
+static int run_two_ranks(const relmc_case_desc* d, const relmc_nsq_opts* o, const relmc_nsq_result* plain)
+{
+    relmc_ctx *c0 = NULL, *c1 = NULL;
+    if (relmc_ctx_create(0, &c0) != RELMC_OK || relmc_ctx_create(0, &c1) != RELMC_OK) return 1;
+    if (relmc_case_load(c0, d) != RELMC_OK || relmc_case_load(c1, d) != RELMC_OK) return 2;
+    two_rank_t t = {c1, o, 0, 0};
+    if (relmc_comm_set_host_allreduce(c0, 2, 0, two_rank_allreduce, &t) != RELMC_OK) return 3;
+    relmc_nsq_result r;
+    if (relmc_nsq_run(c0, o, &r) != RELMC_OK) { fprintf(stderr, "two ranks: %s\n", relmc_last_error(c0)); return 4; }
+    int32_t kind = 0, nr = 0;
+    if (relmc_comm_info(c0, &kind, &nr, NULL, NULL, NULL) != RELMC_OK || kind != 2 || nr != 2) return 5;
+    /* same integers as the one-rank run, sums up to their order, same stopping batch; one all-reduce per batch */
+    if (r.acc.n != plain->acc.n || r.acc.n_fail != plain->acc.n_fail || r.acc.sum_iters != plain->acc.sum_iters || r.checkpoints != plain->checkpoints) return 6;
+    if (memcmp(r.acc.comp_fail, plain->acc.comp_fail, sizeof(r.acc.comp_fail)) != 0) return 7;
+    const double rel = (r.acc.sum_dns - plain->acc.sum_dns) / plain->acc.sum_dns;
+    if (rel > 1e-12 || rel < -1e-12 || t.calls != (int)r.batches || t.done != r.acc.n) return 8;
+    relmc_ctx_destroy(c0); relmc_ctx_destroy(c1);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
@@ -47,7 +81,21 @@ int main(int argc, char** argv)
     if (relmc_comm_unique_id(uid) != RELMC_OK || relmc_comm_init(ctx, 1, 0, uid) != RELMC_OK) { fprintf(stderr, "comm: %s\n", relmc_last_error(ctx)); return 11; }
     if (relmc_comm_allreduce_acc(ctx, &red) != RELMC_OK) { fprintf(stderr, "comm: %s\n", relmc_last_error(ctx)); return 12; }
     if (memcmp(&red, &acc, sizeof(acc)) != 0) return 13;
+    /* relmc_nsq_run with that communicator in the context: the no-communicator result bit for bit (one rank = nothing to split);
+     * the communicator reports its own size */
+    relmc_nsq_opts no; relmc_nsq_opts_default(&no);
+    no.beta_limit = 0.02; no.max_samples = 200000; no.batch = 20000; no.seed = 4;
+    relmc_nsq_result r_comm, r_plain;
+    int32_t kind = -1, nr = -1, rk = -1; int64_t calls = -1; double secs = -1.0;
+    if (relmc_nsq_run(ctx, &no, &r_comm) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 16; }
+    if (relmc_comm_info(ctx, &kind, &nr, &rk, &calls, &secs) != RELMC_OK || kind != 1 || nr != 1 || rk != 0 || calls != 1) return 17;
     relmc_comm_destroy(ctx);
+    if (relmc_comm_info(ctx, &kind, &nr, NULL, NULL, NULL) != RELMC_OK || kind != 0 || nr != 1) return 18;
+    if (relmc_nsq_run(ctx, &no, &r_plain) != RELMC_OK) return 19;
+    if (memcmp(&r_comm.acc, &r_plain.acc, sizeof(relmc_acc)) != 0 || r_comm.idx.beta != r_plain.idx.beta || r_comm.checkpoints != r_plain.checkpoints) return 20;
+    /* the multi-rank loop itself (relmc_nsq_run with R > 1: contiguous split of every batch, one all-reduce per batch) on this one GPU:
+     * a host collective for "2 ranks" whose transport is this process evaluating the OTHER rank's slice on a second context */
+    if (run_two_ranks(&d, &no, &r_plain) != 0) return 21;
     printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
     relmc_ctx_destroy(ctx);
     return 0;
