@@ -329,6 +329,11 @@ int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* con
  * list with their first-attempt results and count them here (0 on every case relmc_case_load calibrated: its primary order fails on at
  * most 0.1 % of the states). */
 int32_t relmc_retry_overflow(const relmc_ctx* ctx, int64_t* units_out);
+/* A unit that no static elimination order converges on is evaluated once more with every Newton step solved by Gaussian elimination
+ * with PARTIAL PIVOTING on the dense reduced system (one scenario row per system, global scratch): what MATLAB's `\` does under MIPS
+ * (mc_simulation.m:41).  Slow and rare (2 units in 1e9 RTS-96 samples reach it); its result takes the earlier attempts' place like theirs.
+ * units_out / converged_out: how many units went there since the case was loaded and how many it converged on. */
+int32_t relmc_retry_dense_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);
 /* relmc_case_load evaluates 8192 sampled states under the primary static order; a case on which more than 0.1 % of them end
  * non-converged gets the further orders probed on the same sample and the best of the three as its primary.  primary_out: 0 = the
  * default (level-then-fill), 1 = the same with the ties broken the other way, 2 = fill first; probe_failures_out: failures of each

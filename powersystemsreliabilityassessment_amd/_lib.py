@@ -25,7 +25,7 @@ EXPORTS = [
     "relmc_nsq_run", "relmc_hl1_load", "relmc_hl1_nsq",
     "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy", "relmc_comm_set_host_allreduce", "relmc_comm_info",
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
-    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_case_order",
+    "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_retry_dense_stats", "relmc_case_order",
 ]
 
 
@@ -127,6 +127,11 @@ def load():
     L.relmc_retry_stats.restype = C.c_int32
     L.relmc_retry_overflow.argtypes = [vp, _abi.c_int64_p]
     L.relmc_retry_overflow.restype = C.c_int32
+    L.relmc_retry_dense_stats.argtypes = [vp, _abi.c_int64_p, _abi.c_int64_p]
+    L.relmc_retry_dense_stats.restype = C.c_int32
+    if hasattr(L, "relmc_debug_mc_simulation_dense"):
+        L.relmc_debug_mc_simulation_dense.argtypes = [vp, u8p, C.c_int64, C.c_void_p, dp, dp, i32p, i32p]
+        L.relmc_debug_mc_simulation_dense.restype = C.c_int32
     L.relmc_case_order.argtypes = [vp, i32p, i32p]
     L.relmc_case_order.restype = C.c_int32
     L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p, u8p]

@@ -229,6 +229,20 @@ class Engine:
             return res + (dict(status=status, iters=iters),)
         return res
 
+    def mc_simulation_dense(self, component_states, mpopt=None):
+        """Test hook: mc_simulation with every Newton step solved by the dense, partially pivoted last resort of the retry path
+        (relmc_debug_mc_simulation_dense).  Returns (dns[n], nodal[n, Nb], dict(status, iters))."""
+        st = np.ascontiguousarray(np.asarray(component_states).reshape(-1, self.case.ncomp) != 0, dtype=np.uint8)
+        n = st.shape[0]
+        o = mpopt if mpopt is not None else mpoption()
+        dns, nodal = np.zeros(n), np.zeros((n, self.case.nb))
+        status, iters = np.zeros(n, dtype=np.int32), np.zeros(n, dtype=np.int32)
+        self._check(self.L.relmc_debug_mc_simulation_dense(self._h, st.ctypes.data_as(_abi.c_uint8_p), n, C.byref(o),
+                                                           dns.ctypes.data_as(_abi.c_double_p), nodal.ctypes.data_as(_abi.c_double_p),
+                                                           status.ctypes.data_as(_abi.c_int32_p), iters.ctypes.data_as(_abi.c_int32_p)),
+                    "relmc_debug_mc_simulation_dense")
+        return dns, nodal, dict(status=status, iters=iters)
+
     def mc_simulation_dev(self, states_ptr: int, n: int, dns_ptr: int, nodal_ptr: int = 0,
                           status_ptr: int = 0, iters_ptr: int = 0, mpopt=None):
         """Same with every buffer already in this GPU's HBM (raw device addresses, e.g. tensor.data_ptr())."""
@@ -291,6 +305,12 @@ class Engine:
         u = C.c_int64()
         self._check(self.L.relmc_retry_overflow(self._h, C.byref(u)), "relmc_retry_overflow")
         return int(u.value)
+
+    def retry_dense_stats(self):
+        """(units that went to the dense, partially pivoted last resort since the case was loaded, how many of them it converged on)."""
+        u, c = C.c_int64(), C.c_int64()
+        self._check(self.L.relmc_retry_dense_stats(self._h, C.byref(u), C.byref(c)), "relmc_retry_dense_stats")
+        return int(u.value), int(c.value)
 
     def case_order(self):
         """(primary static elimination order 0/1/2, failures of each probed order among the 8192 calibration states; -1 = not

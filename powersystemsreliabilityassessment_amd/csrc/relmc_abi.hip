@@ -67,6 +67,8 @@ struct relmc_ctx {
     void* dcase_alt[kAlt] = {nullptr, nullptr}; uint32_t alt_scen_doubles[kAlt] = {0, 0}, alt_lds_bytes[kAlt] = {0, 0}, alt_stash_off[kAlt] = {0, 0};
     FailRec* dfail = nullptr; uint32_t* dfail_count = nullptr; bool fail_dirty = false;
     uint32_t fail_cap = 0;                   // entries of dfail (grows with the size of the call, fail_arm)
+    double* ddense = nullptr; size_t dense_bytes = 0;      // global scratch of the dense pivoted last resort (MODE 6)
+    int64_t retry_dense_units = 0, retry_dense_converged = 0;    // units that went to it since the case was loaded
     bool no_retry = false;                   // RELMC_NO_RETRY, read once at relmc_ctx_create
     int64_t retry_overflow = 0;              // units that did not fit the list and kept their first-attempt results (relmc_retry_overflow)
     std::vector<double> hlf;                 // host copy of the hourly load factors (load scale of a re-evaluated hour)
@@ -154,7 +156,19 @@ int ensure_partial(relmc_ctx* ctx, size_t bytes)
 template <int MODE, class TL>
 int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_start = nullptr, hipEvent_t ev_stop = nullptr, int alt = 0)
 {
-    const int blocks = grid_for<TL>(ctx, a.n);
+    int blocks = grid_for<TL>(ctx, a.n);
+    if (MODE == 6) {
+        // dense last resort: [scenario rows of the grid][2 nb (2 nb + 1)] doubles of scratch; a small grid keeps it small (the units are few)
+        if (blocks > 64) blocks = 64;
+        const size_t n = 2 * (size_t)ctx->nb, stride = n * (n + 1), need = sizeof(double) * stride * (size_t)blocks * TL::WPB * TL::SPW;
+        if (need > ctx->dense_bytes) {
+            if (ctx->ddense) (void)hipFree(ctx->ddense);
+            ctx->ddense = nullptr; ctx->dense_bytes = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->ddense, need));
+            ctx->dense_bytes = need;
+        }
+        a.dense = ctx->ddense; a.dense_stride = stride;
+    }
     int rc = ensure_partial(ctx, sizeof(PartialT<TL>) * 64 * TL::WPB * (size_t)blocks);
     if (rc) return rc;
     a.partial = ctx->dpartial;
@@ -775,6 +789,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
+    HIP_TRY(ctx, hipFuncSetAttribute(reinterpret_cast<const void*>(&relmc_eval_kernel<6, TL>), hipFuncAttributeMaxDynamicSharedMemorySize, (int)ctx->lds_bytes));
     int bpc = 0;
     if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, TL>, 64 * WPB, ctx->lds_bytes) != hipSuccess || bpc < 1) bpc = 1;
 #ifdef RELMC_FORCE_ONE_BLOCK
@@ -909,29 +924,36 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
     // first the whole list under the second order, then whatever is still non-converged under the third (the sets of states the three
     // orders fail on were disjoint on the 67 RTS-96 states of the fixture).  A case without further orders (they do not fit the tile)
     // repeats the primary one, so that the callers' bookkeeping is one path.
-    for (int level = 0; level < relmc_ctx::kAlt; ++level) {
-        const bool have = alt_ensure(ctx, level) == RELMC_OK;
-        if (level > 0 && !have) break;
+    static const bool dense_first = getenv("RELMC_RETRY_DENSE_FIRST") != nullptr;      // tests: the listed units straight to the dense pivoted solve
+    // level 0, 1: the further static orders; level 2: the dense, partially pivoted solve (what MATLAB's `\` does under mips) for whatever
+    // no static order converged on
+    for (int level = dense_first ? relmc_ctx::kAlt : 0; level <= relmc_ctx::kAlt; ++level) {
+        const bool dense = level == relmc_ctx::kAlt;
+        const bool have = dense || alt_ensure(ctx, level) == RELMC_OK;
+        if (level > 0 && !have) continue;
         EvalArgs a = make_args(o);
         a.fail_threshold = fail_threshold;
         a.load_scale = have_scale ? ctx->rscale : nullptr;
         int rows = 0, rc;
-        if (level == 0) {
+        if (level == 0 || (dense && dense_first)) {
             a.n = (int64_t)cnt; a.memo_keys = ctx->rkeys; a.db_first = 0; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
-            rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, have ? 1 : 0);
+            rc = dense ? launch_eval<6>(ctx, a, &rows) : launch_eval<4>(ctx, a, &rows, nullptr, nullptr, have ? 1 : 0);
             if (rc) return rc;
+            if (dense) ctx->retry_dense_units += cnt;
             const double before = ctx->last_kernel_ms;
             rc = finish_timing(ctx);
             if (rc) return rc;
             if (ms) *ms += ctx->last_kernel_ms;
             ctx->last_kernel_ms = before;
             HIP_TRY(ctx, hipMemcpy(out.meta.data(), ctx->rmeta, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));
+            if (dense) for (uint32_t r = 0; r < cnt; ++r) if ((out.meta[r] & 3) == 0 || (out.meta[r] & 3) == 3) ctx->retry_dense_converged += 1;
         } else {
             // what the second order left non-converged, compacted behind the list's rows and evaluated under the third order in ONE launch
             // (round 2 launched once per unit); the results are copied over the rows they belong to
             std::vector<uint32_t> idx;
             for (uint32_t r = 0; r < cnt; ++r) if ((out.meta[r] & 3) == 1 || (out.meta[r] & 3) == 2) idx.push_back(r);
             if (idx.empty()) break;
+            if (dense) ctx->retry_dense_units += (int64_t)idx.size();
             const size_t m = idx.size(), base = (size_t)ctx->rcap;
             std::vector<uint32_t> k2(m * ow); std::vector<double> s2(m);
             for (size_t q = 0; q < m; ++q) { for (int w = 0; w < ow; ++w) k2[q * ow + w] = out.rec[idx[q]].mask[w]; if (have_scale) s2[q] = scale(out.rec[idx[q]].unit); }
@@ -939,7 +961,7 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
             if (have_scale) HIP_TRY(ctx, hipMemcpy(ctx->rscale + base, s2.data(), sizeof(double) * m, hipMemcpyHostToDevice));
             a.n = (int64_t)m; a.memo_keys = ctx->rkeys; a.db_first = (int64_t)base; a.dns = ctx->rdns; a.status = ctx->rmeta; a.nodal = ctx->rnodal;
             a.load_scale = have_scale ? ctx->rscale + base : nullptr;
-            rc = launch_eval<4>(ctx, a, &rows, nullptr, nullptr, level + 1);
+            rc = dense ? launch_eval<6>(ctx, a, &rows) : launch_eval<4>(ctx, a, &rows, nullptr, nullptr, level + 1);
             if (rc) return rc;
             const double before = ctx->last_kernel_ms;
             rc = finish_timing(ctx);
@@ -952,6 +974,13 @@ int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold
                 HIP_TRY(ctx, hipMemcpyAsync(ctx->rnodal + (size_t)idx[q] * nb, ctx->rnodal + (base + q) * nb, sizeof(double) * nb, hipMemcpyDeviceToDevice, ctx->stream));
             }
             HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));
+            if (dense) {
+                std::vector<int32_t> m2(m);
+                HIP_TRY(ctx, hipMemcpy(m2.data(), ctx->rmeta + base, sizeof(int32_t) * m, hipMemcpyDeviceToHost));
+                for (size_t q = 0; q < m; ++q) if ((m2[q] & 3) == 0 || (m2[q] & 3) == 3) ctx->retry_dense_converged += 1;
+            } else {
+                HIP_TRY(ctx, hipMemcpy(out.meta.data(), ctx->rmeta, sizeof(int32_t) * cnt, hipMemcpyDeviceToHost));      // what is still left, for the next level
+            }
         }
     }
     HIP_TRY(ctx, hipMemcpy(out.dns.data(), ctx->rdns, sizeof(double) * cnt, hipMemcpyDeviceToHost));
@@ -1220,6 +1249,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
     if (ctx->dhist) (void)hipFree(ctx->dhist);
     if (ctx->hhist) (void)hipHostFree(ctx->hhist);
+    if (ctx->ddense) (void)hipFree(ctx->ddense);
     for (void* p : {ctx->dcase_alt[0], ctx->dcase_alt[1], (void*)ctx->dfail, (void*)ctx->dfail_count, (void*)ctx->rkeys, (void*)ctx->rdns, (void*)ctx->rmeta, (void*)ctx->rnodal, (void*)ctx->rscale}) if (p) (void)hipFree(p);
     comm_free(ctx);
     pipe_free(ctx);
@@ -1279,6 +1309,7 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
         cc.d.unavail = cc.unavail.data(); cc.d.always_up = cc.always_up.data();
         cc.valid = true;
         ctx->alt_state[0] = ctx->alt_state[1] = 0; ctx->retry_units = 0; ctx->retry_converged = 0; ctx->retry_overflow = 0;
+        ctx->retry_dense_units = 0; ctx->retry_dense_converged = 0;
     }
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
@@ -2551,6 +2582,50 @@ int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, in
     }
     if (err && err_cap > 0) { std::strncpy(err, ctx->err.c_str(), (size_t)err_cap - 1); err[err_cap - 1] = 0; }
     return rc;
+}
+
+// test hook: mc_simulation with EVERY Newton step solved by the dense, partially pivoted last resort (MODE 6) instead of the static
+// sparse schedule -- tests/test_gpu_parity.py compares it with the shipped solver and with the C oracle (whose LU pivots as well)
+int32_t relmc_debug_mc_simulation_dense(relmc_ctx* ctx, const uint8_t* states_host, int64_t n, const relmc_solver_opts* opts, double* dns_host,
+                                        double* nodal_host, int32_t* status_host, int32_t* iters_host)
+{
+    if (!ctx || !ctx->has_case || !states_host || !dns_host || n < 0) return RELMC_ERR_INVALID;
+    if (n == 0) return RELMC_OK;
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    const int ow = ctx->tile == 0 ? Tile24::OW : Tile96::OW, ncomp = ctx->ncomp, nb = ctx->nb;
+    std::vector<uint32_t> keys((size_t)n * ow, 0u);
+    for (int64_t r = 0; r < n; ++r) for (int k = 0; k < ncomp; ++k) if (states_host[(size_t)r * ncomp + k]) keys[(size_t)r * ow + (k >> 5)] |= 1u << (k & 31);
+    uint32_t* dk = nullptr; double* dd = nullptr; int32_t* dm = nullptr; double* dn = nullptr;
+    auto cleanup = [&]() { (void)hipFree(dk); (void)hipFree(dd); (void)hipFree(dm); (void)hipFree(dn); };
+    if (hipMalloc(&dk, sizeof(uint32_t) * keys.size()) != hipSuccess || hipMalloc(&dd, sizeof(double) * (size_t)n) != hipSuccess ||
+        hipMalloc(&dm, sizeof(int32_t) * (size_t)n) != hipSuccess || hipMalloc(&dn, sizeof(double) * (size_t)n * nb) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "dense simulation: device allocation failed"); }
+    int rc = RELMC_OK;
+    if (hipMemcpy(dk, keys.data(), sizeof(uint32_t) * keys.size(), hipMemcpyHostToDevice) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "dense simulation: H2D failed");
+    EvalArgs a = make_args(o);
+    a.n = n; a.memo_keys = dk; a.db_first = 0; a.dns = dd; a.status = dm; a.nodal = dn;
+    int rows = 0;
+    if (rc == RELMC_OK) rc = launch_eval<6>(ctx, a, &rows);
+    if (rc == RELMC_OK) rc = finish_timing(ctx);
+    std::vector<int32_t> meta((size_t)n);
+    if (rc == RELMC_OK && (hipMemcpy(dns_host, dd, sizeof(double) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+                           hipMemcpy(meta.data(), dm, sizeof(int32_t) * (size_t)n, hipMemcpyDeviceToHost) != hipSuccess ||
+                           (nodal_host && hipMemcpy(nodal_host, dn, sizeof(double) * (size_t)n * nb, hipMemcpyDeviceToHost) != hipSuccess)))
+        rc = fail(ctx, RELMC_ERR_HIP, "dense simulation: D2H failed");
+    cleanup();
+    if (rc) return rc;
+    for (int64_t r = 0; r < n; ++r) { if (status_host) status_host[r] = meta[(size_t)r] & 3; if (iters_host) iters_host[r] = (int32_t)((uint32_t)meta[(size_t)r] >> 8); }
+    return RELMC_OK;
+}
+
+// units that went to the dense pivoted last resort since the case was loaded, and how many of them it converged on
+int32_t relmc_retry_dense_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (units_out) *units_out = ctx->retry_dense_units;
+    if (converged_out) *converged_out = ctx->retry_dense_converged;
+    return RELMC_OK;
 }
 
 // profiling hook (only meaningful in -DRELMC_PHASE_TIMING builds): per-phase cycle sums of the last launch

@@ -156,6 +156,9 @@ struct EvalArgs {
     FailRec* fail_list;
     uint32_t fail_cap;
     int64_t unit_base;              // added to the launch-local unit index (chunked host-buffer pipeline)
+    // MODE 6 (dense pivoted last resort): [scenario rows of the grid][dense_stride] doubles of global scratch, dense_stride >= 2 nb (2 nb + 1)
+    double* dense;
+    uint64_t dense_stride;
 };
 
 }  // namespace relmc

@@ -83,6 +83,13 @@ template <int RW> DEVFI uint32_t row_add(uint32_t v)
     if constexpr (RW == 64) v = (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
     return v;
 }
+template <int RW> DEVFI uint32_t row_min_u32(uint32_t v)
+{
+    v = min(v, dppu<0x128>(v)); v = min(v, dppu<0x124>(v)); v = min(v, dppu<0x122>(v)); v = min(v, dppu<0x121>(v));
+    if constexpr (RW == 64) v = min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
+                                    min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
+    return v;
+}
 // does any lane of this scenario row hold `p`?
 template <int RW> DEVFI bool row_any(bool p, int lane)
 {
@@ -183,10 +190,15 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 //         the statistics of the production kernel in a profile
 // MODE 4: new rows of the persistent state database (nsqMain.m:257-278): scenario u = database row db_first + u, state from
 //         the row's key words, results written into the row (dns, status/iterations, nodal shed); no accumulation
+// MODE 6: MODE 4 with a dense, partially pivoted Newton solve in global scratch (a.dense): the last resort of the retry path
 template <int MODE_, class TL>
 __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
-    constexpr int MODE = MODE_ == 5 ? 0 : MODE_;     // 5: the order-calibration probe = the fused path under a kernel name of its own (profiles stay clean)
+    constexpr int MODE = MODE_ == 5 ? 0 : (MODE_ == 6 ? 4 : MODE_);     // 5: the order-calibration probe = the fused path under a kernel name of its own (profiles stay clean)
+    // MODE 6: MODE 4's rows with the Newton step solved DENSE with partial pivoting (the last resort for the units no static elimination
+    // order converges on: MATLAB's `\` under mips, mc_simulation.m:41, pivots too).  The reduced system of order 2 nb lives in a global
+    // scratch matrix per scenario row (RTS-96: 146 x 147 doubles do not fit LDS beside the tables); slow and rare by construction.
+    constexpr bool DENSE = MODE_ == 6;
     constexpr int RW = TL::RW, BS = TL::BS, LS = TL::LS, IS = TL::IS, NBT = TL::NBT, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     using DevCase = DevCaseT<TL>;
     using Partial = PartialT<TL>;
@@ -861,6 +873,34 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
                 // ---- ... then overwrite the workspace (same LDS words as the evaluation arrays) ------
                 RELOAD_FENCE();
+                if constexpr (DENSE) {
+                    // the same blocks into the dense matrix [n x (n + 1)], n = 2 nb, unknowns (theta_0, lambda_0, theta_1, ...), last column = rhs
+                    const int n = 2 * nb, n1 = n + 1;
+                    volatile double* A = a.dense + ((size_t)blockIdx.x * (WPB * SPW) + (size_t)(tid / RW)) * (size_t)a.dense_stride;
+                    for (int e = rlane; e < n * n1; e += RW) A[e] = 0.0;
+                    __threadfence_block();
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) {
+                        if ((linfo[s] >> 24) & LF_OWNER) {
+                            const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
+                            const int hi = f < t ? t : f, lo = f < t ? f : t;
+                            const double c1 = L_C1Z(s) ? 0.0 : cBv[s], c2 = L_C2Z(s) ? 0.0 : cBv[s];
+                            A[(2 * hi) * n1 + 2 * lo] = vown[s]; A[(2 * lo) * n1 + 2 * hi] = vown[s];
+                            A[(2 * hi) * n1 + 2 * lo + 1] = c1; A[(2 * lo + 1) * n1 + 2 * hi] = c1;
+                            A[(2 * hi + 1) * n1 + 2 * lo] = c2; A[(2 * lo) * n1 + 2 * hi + 1] = c2;
+                        }
+                    }
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) {
+                        const int bi = vb[t];
+                        if (bi < nb) {
+                            A[(2 * bi) * n1 + 2 * bi] = d00[t]; A[(2 * bi) * n1 + 2 * bi + 1] = cBd[t];
+                            A[(2 * bi + 1) * n1 + 2 * bi] = cBd[t]; A[(2 * bi + 1) * n1 + 2 * bi + 1] = d11[t];
+                            A[(2 * bi) * n1 + n] = r0[t]; A[(2 * bi + 1) * n1 + n] = r1[t];
+                        }
+                    }
+                    __threadfence_block();
+                } else {
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
                     if ((linfo[s] >> 24) & LF_OWNER) {
@@ -879,6 +919,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         st2(W + 4 * bi, d00[t], cBd[t]); st2(W + 4 * bi + 2, cBd[t], d11[t]);
                         st2(W + off_rhs + 2 * bi, r0[t], r1[t]);
                     }
+                }
                 }
 
                 PT_MARK(2)
@@ -918,6 +959,48 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             if (iterating) {
                 f0 = fval;
                 it += 1;
+                if constexpr (DENSE) {
+                    // ---- Newton step, last resort: Gaussian elimination with partial pivoting on the dense reduced system --------
+                    // lane r of the row owns columns r, r + RW, ... (the rhs is column n); the multipliers of a step are computed by
+                    // all lanes at once and parked in LDS (W is free: the factor is not built), so the row loop reads them there
+                    const int n = 2 * nb, n1 = n + 1;
+                    volatile double* A = a.dense + ((size_t)blockIdx.x * (WPB * SPW) + (size_t)(tid / RW)) * (size_t)a.dense_stride;
+                    double* const Fm = W;                            // [n] multipliers of the current step, then the solution
+                    bool singular_k = false;
+                    for (int k = 0; k < n; ++k) {
+                        double best = -1.0; int bi = n;
+                        for (int i = k + rlane; i < n; i += RW) { const double v = __builtin_fabs(A[(size_t)i * n1 + k]); if (v > best) { best = v; bi = i; } }
+                        const double mx = row_max<RW>(best);
+                        const uint32_t cand = (best == mx) ? (uint32_t)bi : (uint32_t)n;
+                        const int p = (int)row_min_u32<RW>(cand);                                     // lowest row index among the largest entries
+                        if (!(mx > 0.0)) { singular_k = true; break; }                                // exactly singular (or NaN): numerically failed
+                        if (p != k) for (int j = k + rlane; j <= n; j += RW) { const double u = A[(size_t)k * n1 + j], v = A[(size_t)p * n1 + j]; A[(size_t)k * n1 + j] = v; A[(size_t)p * n1 + j] = u; }
+                        __threadfence_block();
+                        const double rp = 1.0 / A[(size_t)k * n1 + k];
+                        for (int i = k + 1 + rlane; i < n; i += RW) Fm[i] = A[(size_t)i * n1 + k] * rp;
+                        RELOAD_FENCE();
+                        for (int i = k + 1; i < n; ++i) {
+                            const double f = Fm[i];
+                            if (f != 0.0) for (int j = k + 1 + rlane; j <= n; j += RW) A[(size_t)i * n1 + j] = A[(size_t)i * n1 + j] - f * A[(size_t)k * n1 + j];
+                        }
+                        __threadfence_block();
+                    }
+                    // back substitution; x in LDS (Fm), then into the solution slots the step phase reads (X[2i] = dtheta_i, X[2i+1] = dlambda_i)
+                    for (int k = n - 1; k >= 0 && !singular_k; --k) {
+                        double sdot = 0.0;
+                        for (int j = k + 1 + rlane; j < n; j += RW) sdot = __builtin_fma(A[(size_t)k * n1 + j], Fm[j], sdot);
+                        sdot = row_sum<RW>(sdot);
+                        if (rlane == 0) Fm[k] = (A[(size_t)k * n1 + n] - sdot) / A[(size_t)k * n1 + k];
+                        RELOAD_FENCE();
+                    }
+                    double xs[(2 * NBT + RW - 1) / RW];
+#pragma unroll
+                    for (int q = 0; q < (2 * NBT + RW - 1) / RW; ++q) { const int e = rlane + RW * q; xs[q] = e < n ? (singular_k ? __builtin_nan("") : Fm[e]) : 0.0; }
+                    RELOAD_FENCE();
+#pragma unroll
+                    for (int q = 0; q < (2 * NBT + RW - 1) / RW; ++q) { const int e = rlane + RW * q; if (e < n) W[off_rhs + e] = xs[q]; }
+                    RELOAD_FENCE();
+                } else {
 #ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
                 // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
@@ -1020,6 +1103,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
                 PT_MARK(5)
 #endif
+                }
                 RELOAD_FENCE();
                 // ---- step lengths ---------------------------------------------------------------------
                 const double* X = W + off_rhs;               // solution: X[2i] = dtheta_i, X[2i+1] = dlambda_i

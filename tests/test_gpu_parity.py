@@ -335,6 +335,40 @@ def test_retry_list_overflow_is_rerun_not_dropped(engine, oracle):
     assert np.array_equal(again.to_arrays()[0], ai) and again.sum_dns == acc.sum_dns
 
 
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_dense_pivoted_last_resort_matches_oracle(engine, oracle, states_fixture, policy):
+    """The last resort of the retry path -- every Newton step by Gaussian elimination with partial pivoting on the dense reduced system
+    (MATLAB's `\\` under mips pivots too, mc_simulation.m:41) -- on all 878 fixture states: status, iteration counts and curtailment of
+    the C oracle (whose LU pivots as well) and of the shipped sparse solver."""
+    st = states_fixture["matrix"]
+    dns, nodal, info = engine.mc_simulation_dense(st, api.mpoption(policy))
+    ref = oracle.mc_simulation(st, policy, nthreads=8)
+    assert np.array_equal(info["status"], ref["status"])
+    np.testing.assert_allclose(dns, ref["dns"], rtol=0, atol=DNS_TOL)
+    dit = np.abs(info["iters"] - ref["iters"])
+    assert dit.max() <= 1 and (dit > 0).mean() < 0.01
+    shed = dns > 0
+    np.testing.assert_allclose(nodal.sum(1)[shed], dns[shed], rtol=0, atol=2e-2)
+    dns2, nodal2, info2 = engine.mc_simulation(st, mpopt=api.mpoption(policy), return_info=True)
+    assert np.array_equal(info["status"], info2["status"]) and np.abs(info["iters"] - info2["iters"]).max() <= 1
+    np.testing.assert_allclose(dns, dns2, rtol=0, atol=DNS_TOL)
+    np.testing.assert_allclose(nodal.sum(0), nodal2.sum(0), rtol=5e-3, atol=1e-6)
+
+
+def test_dense_last_resort_in_the_retry_chain(engine, oracle):
+    """Bookkeeping of the third retry level: with an iteration limit of 7 nothing converges under any order, so every listed unit reaches the
+    dense solve (and stays non-converged there); the accumulators are still the oracle's under the same limit."""
+    o = api.mpoption(api.REFERENCE_EMULATE); o.max_it = 7
+    d0 = engine.retry_dense_stats()
+    acc = engine.nsq_accumulate(5, 0, 3000, o)
+    d1 = engine.retry_dense_stats()
+    ref = oracle.nsq_accumulate(5, 0, 3000, api.REFERENCE_EMULATE, opts=o)
+    assert acc.n_nonconverged == ref.n_nonconverged > 1000
+    assert d1[0] - d0[0] == acc.n_nonconverged and d1[1] == d0[1]
+    assert (acc.n_fail, acc.n_singular, acc.sum_iters) == (ref.n_fail, ref.n_singular, ref.sum_iters)
+    assert acc.sum_dns == pytest.approx(ref.sum_dns, rel=1e-7)
+
+
 # ---- the reference's persistent unique-state database on the device (nsqMain.m:91-99, 220-278) -------------------------
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
 def test_state_database_matches_oracle_database(engine, oracle, policy):
