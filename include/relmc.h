@@ -343,7 +343,11 @@ int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t pro
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
 /* Batches of up to 8192 samples (the reference's is 100, nsqMain.m:60) are evaluated many at a time in the modes
  * distinct_states = 0 and 2; every checkpoint's history entry and the stopping point are those of the batch-by-batch loop
- * (DESIGN.md 6.8).  RELMC_NSQ_NO_STRETCH=1 in the environment forces one launch per batch (diagnosis). */
+ *  up to fp64 summation order: inside a stretch the checkpoints' EDNS / beta come from host sums of the per-sample dns
+ * (the last checkpoint of a stretch, and with it the result, from the device accumulators themselves), which differ from the
+ * batch-by-batch device sums in the last bits; integers (samples, loss counts, the stopping batch on any beta not within 1e-12 of its
+ * limit) are identical.  A stretch that is cut at the stopping batch is evaluated again over the shorter range; its first evaluation
+ * leaves no trace in relmc_retry_stats or kernel_seconds.  RELMC_NSQ_NO_STRETCH=1 forces one launch per batch (diagnosis). */
 int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);
 
 #ifdef __cplusplus

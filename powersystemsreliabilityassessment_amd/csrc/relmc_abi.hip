@@ -2286,6 +2286,9 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
             relmc_acc part;
             int rc;
             const int64_t rows0 = ctx->db_n, samples0 = ctx->db_samples;
+            // what a stretch that is cut and taken again must not count twice: its second attempts, its kernel time
+            const int64_t ru0 = ctx->retry_units, rc0_ = ctx->retry_converged, rd0 = ctx->retry_dense_units, rdc0 = ctx->retry_dense_converged, ro0 = ctx->retry_overflow;
+            const double kernel_ms0 = kernel_ms;
             if (use_db) {
                 if (rows0 > ctx->db_snap_cap) {
                     if (ctx->db_snap) (void)hipFree(ctx->db_snap);
@@ -2324,6 +2327,10 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
                 beta = ix.beta;
                 checkpoint(ix);
                 if (beta <= o->beta_limit) break;
+            }
+            if (used < m) {                                    // the discarded stretch leaves no trace in the bookkeeping
+                ctx->retry_units = ru0; ctx->retry_converged = rc0_; ctx->retry_dense_units = rd0; ctx->retry_dense_converged = rdc0; ctx->retry_overflow = ro0;
+                kernel_ms = kernel_ms0;
             }
             if (used < m && use_db) {                          // stopped inside the stretch: the database as it was, then the shorter range
                 ctx->db_n = rows0; ctx->db_samples = samples0;

@@ -179,6 +179,15 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define PT_MARK(k)
 #define PT_FLUSH
 #endif
+// -DRELMC_PHASE_TIMING -DRELMC_PT_INIT: the per-scenario-group setup split instead (0 window sampling, 1 state from the window / masks,
+// 2 status -> model, 3 topology, 4 susceptance entries, 5 start point; 6 = the whole interior-point loop, 7 = output)
+#if defined(RELMC_PHASE_TIMING) && defined(RELMC_PT_INIT)
+#undef PT_MARK
+#define PT_MARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_[(k) == 7 ? 7 : 6] += n_ - pt0_; pt0_ = n_; }
+#define PT_IMARK(k) { const unsigned long long n_ = __builtin_readcyclecounter(); pt_[k] += n_ - pt0_; pt0_ = n_; }
+#else
+#define PT_IMARK(k)
+#endif
 
 // MODE 0: fused non-sequential path (states from the counter-based sampler, accumulators only)
 // MODE 1: explicit states (+ optional per-scenario load scale), per-scenario results written out
@@ -256,7 +265,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // injection bounds on the wide tile (-1.8 %; +0.6 % on the narrow one).  Cost and incidence lists in registers: neutral / +14 %.
     // ... per instantiation: the instantiations that write per-scenario results or walk the chronology (MODE 1, 2, 4) carry more live state
     // and lose 2-3 % with the line values in registers (measured on MODE 1 and 2), the fused ones gain 1-2 %
+#ifdef RELMC_LTAB_LDS_ALL      // A/B of the scratch traffic (profiles/r3_final/scratch_ab.log): every instantiation reads the line values from LDS
+    constexpr bool LTAB_LDS = true;
+#else
     constexpr bool LTAB_LDS = (MODE == 1 || MODE == 2 || MODE == 4);
+#endif
     double lbv_[LS], lrv_[LS], ihi_[IS], ilo_[IS];
 #pragma unroll
     for (int s = 0; s < LS; ++s) { lbv_[s] = LTAB_LDS ? 0.0 : TABL.l_b[RW * s + rlane]; lrv_[s] = LTAB_LDS ? 0.0 : TABL.l_rate[RW * s + rlane]; }
@@ -362,6 +375,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         win_valid = n_valid;
         win_groups = (int)((n_valid + 3u) >> 2);
     }
+    PT_IMARK(0)
     for (int wg = 0; wg < win_groups; ++wg) {
         const int64_t grp = WINDOWED ? wb + wg : wb;
         const int64_t sidx = grp * SPW + lane / RW;
@@ -458,6 +472,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             }
             RELOAD_FENCE();
 
+            PT_IMARK(1)
             // ===== mc_simulation.m:32-37: component status -> model ==========================
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
@@ -480,6 +495,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             for (int s = 0; s < LS; ++s) lout = lout || (((linfo[s] >> 24) & LF_EXISTS) && !L_ON(s));
             const bool any_lout = C.base_connected == 0 || row_any<RW>(lout, lane);
 
+            PT_IMARK(2)
             // ===== topology: isolated buses, islands, island rules (DESIGN.md "island policy") ==========
             if constexpr (RW == 16) {
                 // 16-lane tile: bus sets are 32-bit masks in registers
@@ -679,6 +695,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
             }
 
+            PT_IMARK(3)
             // ===== constant (per scenario) susceptance entries of the KKT blocks, pins/drops masked ==
 #pragma unroll
             for (int s = 0; s < LS; ++s) {
@@ -707,6 +724,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 }
             }
 
+            PT_IMARK(4)
             // ===== dcopf_solver start point + mips initialisation (SURVEY.md Appendix B 2,4) =====
             double fl = 0.0;
             uint32_t nq = 0;
@@ -748,6 +766,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
             status = singular ? 3 : 0;
         }
 
+        PT_IMARK(5)
         PT_MARK(0)
         // ===== mips main loop =======================================
         while (__any(iterating)) {
