@@ -1203,7 +1203,7 @@ int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, in
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.5 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules, device state database)"; }
+const char* relmc_version(void) { return "relmc 0.6 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules + dense pivoted last resort, device state database, multi-rank loop)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
