@@ -1065,13 +1065,13 @@ int order_calibrate(relmc_ctx* ctx)
         if (ctx->tile == 0) {
             for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile24>),
                                   reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile24>),
-                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile24>)})
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile24>), reinterpret_cast<const void*>(&relmc_eval_kernel<6, Tile24>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile24>, 64 * Tile24::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
         } else {
             for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, Tile96>),
                                   reinterpret_cast<const void*>(&relmc_eval_kernel<3, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<4, Tile96>),
-                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile96>)})
+                                  reinterpret_cast<const void*>(&relmc_eval_kernel<5, Tile96>), reinterpret_cast<const void*>(&relmc_eval_kernel<6, Tile96>)})
                 if (e == hipSuccess) e = hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, lds > (int)ctx->alt_lds_bytes[v] ? lds : (int)ctx->alt_lds_bytes[v]);
             if (hipOccupancyMaxActiveBlocksPerMultiprocessor(&bpc, relmc_eval_kernel<0, Tile96>, 64 * Tile96::WPB, ctx->lds_bytes) == hipSuccess && bpc >= 1) ctx->blocks_per_cu = bpc;
         }
