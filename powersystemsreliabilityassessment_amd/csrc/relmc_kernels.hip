@@ -108,21 +108,32 @@ DEVFI double frcp(double x)
     return __builtin_fma(r, __builtin_fma(e, e, e), r);
 }
 // 1/a and 1/b from ONE reciprocal: R = 1/(a b), 1/a = b R, 1/b = a R (a v_rcp_f64 is quarter rate and wants its correction, two
-// multiplications are cheaper; ~2 ulp instead of ~1).  Measured in round 3 for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of
-// every two-sided bound: -1.5 % / -0.8 % kernel time on RTS-24 / RTS-96 -- and NOT shipped (-DRELMC_RPAIR builds it): any change of a
-// rounding here, even in the ratio tests alone, moves the state "G24 + G33 out" (0.3 % of all RTS-24 samples) from 14 to 15 iterations,
-// because at gamma ~ 1e-8 the Newton step of the static-order factorisation carries enough noise along the LP's degenerate optimal face
-// to cut one dual step (alpha_d 0.57 instead of 1, scripts/trace24.py); the extra iteration moves that state's nodal split by 6 MW on a
-// bus and with it one bus' nodal sum of a sampled run by 2 % against the oracle (profiles/r3_rcp/).  The round-2 arithmetic happens to
-// take the oracle's 14 iterations there; the cubic frcp above reproduces it bit for bit.
+// multiplications are cheaper; ~2 ulp instead of ~1), for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of a two-sided bound.
+// Round 3 measured it per call site (profiles/r3_rcp/pair_sites.log): at ALL eight sites -1.5 % / -0.8 % kernel time on RTS-24 / RTS-96, but the
+// state "G24 + G33 out" (0.3 % of all RTS-24 samples) moves from the oracle's 14 iterations to 15 -- at gamma ~ 1e-8 the Newton step of the
+// static-order factorisation carries enough noise along the LP's degenerate optimal face that one more rounding cuts a dual step (alpha_d 0.57
+// instead of 1, scripts/trace24.py), the extra iteration moves that state's nodal split by 6 MW on a bus and one bus' nodal sum of a sampled run
+// by 2 % against the oracle.  The injection evaluation (site 1) does that on its own, the injections' ratio-test multipliers (site 5) move
+// another fixture state, and combinations are not additive (0xDD and 0xD5 flip it again).  Shipped: the mask below -- line evaluation, the
+// lines' ratio tests, both updates -- under which every one of the 878 + 317 fixture states keeps its iteration count and 8 of 1e6 sampled
+// scenarios change theirs by one (-1.2 % kernel time).  On the 64-lane tile the same mask is 1.5 % SLOWER (the wide tile is bound by its chain, and
+// the pair form is one multiplication longer) and moves which RTS-96 states the primary order fails on, which the retry tests pin: it stays at the
+// round-2 arithmetic, bit for bit.  -DRELMC_RPAIR_MASK=0 gives that on both tiles, 0xff all sites.
+#ifndef RELMC_RPAIR_MASK
+#define RELMC_RPAIR_MASK 0xCD       // 16-lane tile.  bit 0 / 1 evaluation lines / injections, 2 / 4 ratio-test slacks (lines / injections), 3 / 5 ratio-test multipliers, 6 / 7 update lines / injections
+#endif
+#ifndef RELMC_RPAIR_MASK_WIDE
+#define RELMC_RPAIR_MASK_WIDE 0     // 64-lane tile
+#endif
+template <bool PAIR>
 DEVFI void frcp_pair(double a, double b, double& ra, double& rb)
 {
-#ifdef RELMC_RPAIR
-    const double R = frcp(a * b);
-    ra = b * R; rb = a * R;
-#else
-    ra = frcp(a); rb = frcp(b);
-#endif
+    if constexpr (PAIR) {
+        const double R = frcp(a * b);
+        ra = b * R; rb = a * R;
+    } else {
+        ra = frcp(a); rb = frcp(b);
+    }
 }
 
 // 1/x to ~2e-15 relative (measured on gfx950: raw v_rcp_f64 4.4e-8, one Newton step 2.0e-15, two steps exact):
@@ -132,14 +143,15 @@ DEVFI double frcp1(double x)
     const double r = __builtin_amdgcn_rcp(x);
     return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
 }
+template <bool PAIR>
 DEVFI void frcp1_pair(double a, double b, double& ra, double& rb)
 {
-#ifdef RELMC_RPAIR
-    const double R = frcp1(a * b);
-    ra = b * R; rb = a * R;
-#else
-    ra = frcp1(a); rb = frcp1(b);
-#endif
+    if constexpr (PAIR) {
+        const double R = frcp1(a * b);
+        ra = b * R; rb = a * R;
+    } else {
+        ra = frcp1(a); rb = frcp1(b);
+    }
 }
 
 // Philox4x32-10 (Salmon et al. SC'11); counter (i_lo, i_hi, block, 0), key = seed
@@ -208,6 +220,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // order converges on: MATLAB's `\` under mips, mc_simulation.m:41, pivots too).  The reduced system of order 2 nb lives in a global
     // scratch matrix per scenario row (RTS-96: 146 x 147 doubles do not fit LDS beside the tables); slow and rare by construction.
     constexpr bool DENSE = MODE_ == 6;
+    constexpr int PAIR_MASK = TL::RW == 16 ? RELMC_RPAIR_MASK : RELMC_RPAIR_MASK_WIDE;      // which call sites share a reciprocal (frcp_pair)
+#define PAIRSITE(k) (((PAIR_MASK >> (k)) & 1) != 0)
     constexpr int RW = TL::RW, BS = TL::BS, LS = TL::LS, IS = TL::IS, NBT = TL::NBT, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     using DevCase = DevCaseT<TL>;
     using Partial = PartialT<TL>;
@@ -785,7 +799,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (L_ACT(s)) {
                         const double b = lb(s), rr = lr(s);
                         const double hp = LFv[s] - rr, hm = -LFv[s] - rr;
-                        double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
+                        double rzp, rzm; frcp_pair<PAIRSITE(0)>(lzp[s], lzm[s], rzp, rzm);
                         g = b * b * (lmup[s] * rzp + lmum[s] * rzm);
                         lx = __builtin_fma(b, lmup[s] - lmum[s], lx);
                         q = b * ((lmup[s] * hp + gamma) * rzp - (lmum[s] * hm + gamma) * rzm);
@@ -807,7 +821,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (I_BOX(s)) {
                         const d2 hl = IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
-                        double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
+                        double rzp, rzm; frcp_pair<PAIRSITE(1)>(izp[s], izm[s], rzp, rzm);
                         const double D = imup[s] * rzp + imum[s] * rzm;
                         const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
@@ -1155,12 +1169,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                            double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
+                            double rzp, rzm; frcp_pair<PAIRSITE(2)>(lzp[s], lzm[s], rzp, rzm);
                             const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
                             const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
                             // ratio tests without divisions by the steps: min_k z_k/(-dz_k) = 1 / max_k(-dz_k/z_k)
                             tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
-                            double rmp, rmm; frcp1_pair(lmup[s], lmum[s], rmp, rmm);
+                            double rmp, rmm; frcp1_pair<PAIRSITE(3)>(lmup[s], lmum[s], rmp, rmm);
                             td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                         }
                     }
@@ -1179,11 +1193,11 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                            double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
+                            double rzp, rzm; frcp_pair<PAIRSITE(4)>(izp[s], izm[s], rzp, rzm);
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
                             const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
                             tp = vmax(tp, vmax(-dzp * rzp, -dzm * rzm));
-                            double rmp, rmm; frcp1_pair(imup[s], imum[s], rmp, rmm);
+                            double rmp, rmm; frcp1_pair<PAIRSITE(5)>(imup[s], imum[s], rmp, rmm);
                             td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
@@ -1216,7 +1230,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
-                            double rzp, rzm; frcp_pair(lzp[s], lzm[s], rzp, rzm);
+                            double rzp, rzm; frcp_pair<PAIRSITE(6)>(lzp[s], lzm[s], rzp, rzm);
                             const double dmup = -lmup[s] + (gamma - lmup[s] * dzp) * rzp;
                             const double dmum = -lmum[s] + (gamma - lmum[s] * dzm) * rzm;
                             lzp[s] = __builtin_fma(alphap, dzp, lzp[s]); lzm[s] = __builtin_fma(alphap, dzm, lzm[s]);
@@ -1234,7 +1248,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
-                            double rzp, rzm; frcp_pair(izp[s], izm[s], rzp, rzm);
+                            double rzp, rzm; frcp_pair<PAIRSITE(7)>(izp[s], izm[s], rzp, rzm);
                             const double dmup = -imup[s] + (gamma - imup[s] * dzp) * rzp;
                             const double dmum = -imum[s] + (gamma - imum[s] * dzm) * rzm;
                             ip[s] = __builtin_fma(alphap, dpv[s], ip[s]);

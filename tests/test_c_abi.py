@@ -40,7 +40,14 @@ def test_plain_c_client(tmp_path, case):
                      (case.inj_cost, np.float64), (case.br_from, np.int32), (case.br_to, np.int32), (case.br_b, np.float64),
                      (case.br_rate, np.float64), (case.unavail, np.float64), (case.always_up, np.uint8)):
             fh.write(np.ascontiguousarray(a, dtype=t).tobytes())
-    out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=300)
+    out = None
+    for attempt in range(2):                      # the client takes ~7 s; one run in ~15 on the GPU pool stalled inside RCCL's one-rank bootstrap
+        try:
+            out = subprocess.run([exe, str(f)], capture_output=True, text=True, timeout=240)
+            break
+        except subprocess.TimeoutExpired:
+            if attempt == 1:
+                raise
     assert out.returncode == 0, out.stderr
     n, n_fail, sum_dns, nd = out.stdout.strip().splitlines()[-1].split()[:4]      # RCCL prints a banner before it
     from powersystemsreliabilityassessment_amd import api
