@@ -4,7 +4,7 @@ Model of the update phase of the sparse 2x2-block LDL' (one bus per pivot): a ta
 target block run one per pass in pivot order (read-modify-write chains), unlimited lanes.  Simulated annealing over the elimination order
 (reference bus last) minimises  max(critical path, tasks / lanes) + 0.6 (tree height - 1)  = update passes + back-substitution passes.
 
-Result (DESIGN.md 3.2, round 3): RTS-24 11 / 8 (critical path / tree height) under the shipped level-then-fill rule, nothing better found;
+Result (DESIGN_HISTORY.md H3, round 3): RTS-24 11 / 8 (critical path / tree height) under the shipped level-then-fill rule, nothing better found;
 RTS-96 19 / 12 shipped, 17 / 11 at best -- a nested-dissection order has nothing to offer, the shipped trees are as shallow as these graphs allow.
     python scripts/order_search.py
 """
