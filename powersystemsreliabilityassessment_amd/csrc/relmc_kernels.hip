@@ -786,6 +786,20 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         while (__any(iterating)) {
             if (prio_first) { if ((__builtin_readcyclecounter() >> 15) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
             RELOAD_FENCE();
+            // The per-slot conditions (slot in service / boxed / owner / pinned ...) are loop invariant, so the compiler hoists them out of the
+            // interior-point loop as 64-bit lane masks: ~45 masks, 163 SGPRs spilled to VGPR lanes, and the VGPRs those push out go to scratch.
+            // Hiding the words they derive from once per iteration makes it re-derive them where they are used (a v_and + v_cmp instead of two
+            // v_readlane): scratch 284 -> 164 B/lane and HBM traffic 530 -> 219 B per scenario at the same kernel time on the 16-lane tile
+            // (round 3, profiles/r3_final/scratch_ab.log; results bit-identical).  The 64-lane tile loses 1.5 % with it and keeps the masks.
+            if constexpr (RW == 16) {
+                __asm__ volatile("" : "+v"(sf));
+#pragma unroll
+                for (int s = 0; s < LS; ++s) __asm__ volatile("" : "+v"(linfo[s]));
+#pragma unroll
+                for (int s = 0; s < IS; ++s) __asm__ volatile("" : "+v"(iinfo[s]));
+#pragma unroll
+                for (int t = 0; t < BS; ++t) __asm__ volatile("" : "+v"(vb[t]));
+            }
             if (iterating) {
                 // ---- evaluate h, Lx, barrier terms; scatter to LDS; convergence norms -------------
                 double mx_gh = -DINF, mx_x = 0.0, mx_z = 0.0, mx_lx = 0.0, mx_lammu = 0.0;
