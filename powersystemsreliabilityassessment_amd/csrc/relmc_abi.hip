@@ -174,7 +174,7 @@ int launch_eval_t(relmc_ctx* ctx, EvalArgs& a, int* rows_out, hipEvent_t ev_star
     a.partial = ctx->dpartial;
     a.scen_doubles = alt ? ctx->alt_scen_doubles[alt - 1] : ctx->scen_doubles;
     // the grid fills the device: first-dispatched and later wavefronts share every SIMD (see the kernel's priority balancing)
-    a.prio_mode = blocks != ctx->num_cu * ctx->blocks_per_cu ? 0u : (ctx->blocks_per_cu == 2 ? 1u : (ctx->blocks_per_cu == 1 && TL::WPB == 8 ? 2u : 0u));
+    a.prio_mode = blocks != ctx->num_cu * ctx->blocks_per_cu ? 0u : (ctx->blocks_per_cu == 2 ? 1u : (ctx->blocks_per_cu == 1 && TL::WPB >= 8 ? 2u : 0u));
     a.stash_off = alt ? ctx->alt_stash_off[alt - 1] : ctx->stash_off;
     a.case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);
 #if defined(RELMC_PHASE_TIMING) || defined(RELMC_TRACE)
@@ -311,7 +311,19 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
     struct Task { uint8_t kind; uint16_t o[4]; std::vector<int> rd, wr; };
     std::vector<Task> tasks;
     auto unit = [&](int off) { return off < (int)C.off_rhs ? off >> 2 : (int)C.off_rhs / 4 + ((off - (int)C.off_rhs) >> 1); };   // one block / one rhs pair
+    // model only (RELMC_MODEL_LEAF_FREE, with RELMC_VERBOSE): what would the update phase look like if the pivots that are complete at
+    // assembly (no earlier-eliminated neighbour) were eliminated by the assembling lanes?  The printed schedule is NOT a valid program.
+    std::vector<char> leaf_free(nb, 0);
+    if (getenv("RELMC_MODEL_LEAF_FREE")) {
+        const int maxdeg_free = atoi(getenv("RELMC_MODEL_LEAF_FREE"));
+        std::vector<char> has_lower(nb, 0);
+        for (int i = 0; i < nb; ++i) for (int a2 : N[i]) has_lower[a2] = 1;
+        int nfree = 0, ntask_free = 0;
+        for (int i = 0; i < nb; ++i) if (!has_lower[i] && (int)N[i].size() <= maxdeg_free) { leaf_free[i] = 1; nfree++; ntask_free += (int)(N[i].size() * (N[i].size() + 1) / 2 + N[i].size()); }
+        fprintf(stderr, "relmc: model: %d pivots complete at assembly with <= %d higher neighbours, %d update tasks\n", nfree, maxdeg_free, ntask_free);
+    }
     for (int i = 0; i < nb; ++i) {
+        if (leaf_free[i]) continue;
         for (size_t ia = 0; ia < N[i].size(); ++ia)
             for (size_t ib = 0; ib <= ia; ++ib) {
                 const int a2 = N[i][ia], b2 = N[i][ib];

@@ -122,6 +122,9 @@ DEVFI double frcp(double x)
 #ifndef RELMC_RPAIR_MASK
 #define RELMC_RPAIR_MASK 0xCD       // 16-lane tile.  bit 0 / 1 evaluation lines / injections, 2 / 4 ratio-test slacks (lines / injections), 3 / 5 ratio-test multipliers, 6 / 7 update lines / injections
 #endif
+#ifndef RELMC_INJ_NFORM
+#define RELMC_INJ_NFORM 1           // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
+#endif
 #ifndef RELMC_RPAIR_MASK_WIDE
 #define RELMC_RPAIR_MASK_WIDE 0     // 64-lane tile
 #endif
@@ -181,6 +184,24 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define RELOAD_FENCE() __asm__ volatile("" ::: "memory")
 // keeps the unrolled per-slot bodies from being interleaved (each body has ~20 live temporaries)
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
+// A/B (RELMC_FENCE_MASK, default all six sites): bit k = 0 lets the scheduler interleave the slot bodies of site k
+// (0 / 1 evaluation lines / injections, 2 / 3 ratio tests, 4 / 5 update)
+#ifndef RELMC_FENCE_MASK
+#define RELMC_FENCE_MASK 0x3f
+#endif
+// LDS round trips of the vector phases taken off the wavefront's critical path (RELMC_PF_MASK, bit k = site k): operands of the NEXT slot
+// are requested before the current slot is worked on, and loads that sat in separate branches are issued as one batch.  Same arithmetic.
+//   0 evaluation: injection bounds / cost / lambda one slot ahead      1 assembly: block offsets before the gathers
+//   2 gathers: incidence lists of both bus slots up front              3 step: the lines' and injections' solution entries as one batch
+//   4 / 5 ratio tests / update: injection bounds (and cost) one slot ahead    6 / 7 step / convergence test: solver options requested before the row reductions
+#ifndef RELMC_PF_MASK
+#define RELMC_PF_MASK 0xc8          // 16-lane tile: sites 3, 6, 7 (-1.4 % kernel time; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
+#endif
+#ifndef RELMC_PF_MASK_WIDE
+#define RELMC_PF_MASK_WIDE 0xc6     // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
+#endif
+#define PFSITE(k) (((PF_MASK >> (k)) & 1) != 0)
+#define SLOT_FENCE_AT(k) do { if constexpr (((RELMC_FENCE_MASK >> (k)) & 1) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 // optional per-phase cycle accounting (profiling builds only: -DRELMC_PHASE_TIMING)
 #ifdef RELMC_PHASE_TIMING
 #define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt0_ = __builtin_readcyclecounter();
@@ -222,6 +243,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     constexpr bool DENSE = MODE_ == 6;
     constexpr int PAIR_MASK = TL::RW == 16 ? RELMC_RPAIR_MASK : RELMC_RPAIR_MASK_WIDE;      // which call sites share a reciprocal (frcp_pair)
 #define PAIRSITE(k) (((PAIR_MASK >> (k)) & 1) != 0)
+    constexpr int PF_MASK = TL::RW == 16 ? RELMC_PF_MASK : RELMC_PF_MASK_WIDE;                 // which LDS round trips are taken off the critical path (PFSITE)
     constexpr int RW = TL::RW, BS = TL::BS, LS = TL::LS, IS = TL::IS, NBT = TL::NBT, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     using DevCase = DevCaseT<TL>;
     using Partial = PartialT<TL>;
@@ -284,14 +306,19 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #else
     constexpr bool LTAB_LDS = (MODE == 1 || MODE == 2 || MODE == 4);
 #endif
+#ifdef RELMC_ITAB_MEM          // A/B: the wide tile reads the injection bounds from the table too (register diet for a third wave per SIMD)
+    constexpr bool ITAB_REG = false;
+#else
+    constexpr bool ITAB_REG = RW == 64;
+#endif
     double lbv_[LS], lrv_[LS], ihi_[IS], ilo_[IS];
 #pragma unroll
     for (int s = 0; s < LS; ++s) { lbv_[s] = LTAB_LDS ? 0.0 : TABL.l_b[RW * s + rlane]; lrv_[s] = LTAB_LDS ? 0.0 : TABL.l_rate[RW * s + rlane]; }
 #pragma unroll
-    for (int s = 0; s < IS; ++s) { ihi_[s] = RW == 64 ? TABI.i_tab[RW * s + rlane][0] : 0.0; ilo_[s] = RW == 64 ? TABI.i_tab[RW * s + rlane][1] : 0.0; }
+    for (int s = 0; s < IS; ++s) { ihi_[s] = ITAB_REG ? TABI.i_tab[RW * s + rlane][0] : 0.0; ilo_[s] = ITAB_REG ? TABI.i_tab[RW * s + rlane][1] : 0.0; }
 #define lb(s) (LTAB_LDS ? TABL.l_b[RW * (s) + rlane] : lbv_[s])
 #define lr(s) (LTAB_LDS ? TABL.l_rate[RW * (s) + rlane] : lrv_[s])
-#define IHL(s, j) (RW == 64 ? d2{ihi_[s], ilo_[s]} : ld2(TABI.i_tab[j]))
+#define IHL(s, j) (ITAB_REG ? d2{ihi_[s], ilo_[s]} : ld2(TABI.i_tab[j]))
 #define ICOST(s, j) TABI.i_tab[j][2]
 #define PLIST(t, bi) TABG.b_line8[bi]
 #define JLIST(t, bi) TABG.b_inj8[bi]
@@ -328,7 +355,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // when two workgroups share a CU; 2: first half of the waves of the workgroup) alternates between the lowest and the
     // highest user priority on a clock bit, the other half stays in between: each wavefront wins the arbitration half of
     // the TIME.  The work assignment stays static, so results are unchanged and reproducible.
-    const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? (tid >> 6) < WPB / 2 : false);
+    const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? ((tid >> 8) & 1) == 0 : false);      // mode 2: the waves that came first on their SIMD (0-3; 8-11 behind 4-7)
     if (a.prio_mode != 0 && !prio_first) __builtin_amdgcn_s_setprio(1);
     // Fused non-sequential path on the 16-lane tile: every wavefront owns a contiguous range of scenario groups and walks
     // it in windows of 64 scenarios.  The window's states are sampled up front, one scenario per lane, and ordered so that
@@ -823,8 +850,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     gown[s] = g;
                     if (l < nlp) { st2(LR + 4 * l, g, lx); st2(LR + 4 * l + 2, lx + q, LFv[s]); }   // nl / ninj records (they alias W)
-                    SLOT_FENCE();
+                    SLOT_FENCE_AT(0);
                 }
+                d2 ev_hl = d2{0.0, 0.0}; double ev_co = 0.0, ev_la = 0.0;
+                if constexpr (PFSITE(0)) { ev_hl = IHL(0, rlane); ev_co = ICOST(0, rlane); ev_la = Lam[iinfo[0] & 0xff]; }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
@@ -832,14 +861,26 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     const double pv = ip[s];         // stays 0 on an injection out of service
                     mx_x = vmax(mx_x, __builtin_fabs(pv));
                     nanx = nanx || pv != pv;
+                    const d2 hl_pf = ev_hl; const double co_pf = ev_co, la_pf = ev_la;
+                    if constexpr (PFSITE(0)) if (s + 1 < IS) { ev_hl = IHL(s + 1, RW * (s + 1) + rlane); ev_co = ICOST(s + 1, RW * (s + 1) + rlane); ev_la = Lam[iinfo[s + 1 < IS ? s + 1 : s] & 0xff]; }
                     if (I_BOX(s)) {
-                        const d2 hl = IHL(s, j);               // {upper, lower} bound
+                        const d2 hl = PFSITE(0) ? hl_pf : IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
+                        const double lxp = (PFSITE(0) ? co_pf : ICOST(s, j)) - (PFSITE(0) ? la_pf : Lam[iinfo[s] & 0xff]) + (imup[s] - imum[s]);
+                        if constexpr (RW == 16 && RELMC_INJ_NFORM) {
+                            // D = N / (z+ z-) with N = mu+ z- + mu- z+: 1/D and Np/D from ONE reciprocal (of N) instead of three (round 3: -1.9 %
+                            // kernel time; no fixture state changes its iteration count, 6 of 1e6 sampled scenarios do by one).  The 64-lane tile keeps
+                            // its round-2 arithmetic (see RELMC_RPAIR_MASK_WIDE).
+                            const double N = __builtin_fma(imup[s], izm[s], imum[s] * izp[s]);
+                            const double rN = frcp(N), zz = izp[s] * izm[s];
+                            invD = zz * rN;
+                            npd = __builtin_fma(lxp, zz, (imup[s] * hp + gamma) * izm[s] - (imum[s] * hm + gamma) * izp[s]) * rN;
+                        } else {
                         double rzp, rzm; frcp_pair<PAIRSITE(1)>(izp[s], izm[s], rzp, rzm);
                         const double D = imup[s] * rzp + imum[s] * rzm;
-                        const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         const double np = lxp + (imup[s] * hp + gamma) * rzp - (imum[s] * hm + gamma) * rzm;
                         invD = frcp(D); npd = np * invD;
+                        }
                         mx_lx = vmax(mx_lx, __builtin_fabs(lxp));
                         mx_gh = vmax(mx_gh, vmax(hp, hm));
                         mx_z = vmax(mx_z, vmax(izp[s], izm[s]));
@@ -847,21 +888,30 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     if (j < nip) IR[j] = pv;
                     st2(Stash + 2 * RW * s, invD, npd);
-                    SLOT_FENCE();
+                    SLOT_FENCE_AT(1);
                 }
                 PT_MARK(1)
                 if (rlane == 0) { st2(LR + 4 * nlp, 0.0, 0.0); st2(LR + 4 * nlp + 2, 0.0, 0.0); IR[nip] = 0.0; }
                 // ---- assemble: gather everything the KKT blocks need into registers ... -------------
-                double vown[LS];
+                uint32_t lblk_pf[LS]; uint32_t zo_pf = 0;
+                if constexpr (PFSITE(1)) {
 #pragma unroll
-                for (int s = 0; s < LS; ++s) {
-                    vown[s] = 0.0;
-                    const uint32_t inf = linfo[s];
-                    if ((inf >> 24) & LF_OWNER) {
-                        double gs = gown[s];
-                        if (lpart[s] >= 0) gs += LR[4 * lpart[s]];
-                        vown[s] = L_PIN(s) ? 0.0 : -gs;   // pinned columns removed
-                    }
+                    for (int s = 0; s < LS; ++s) lblk_pf[s] = C.l_blk[RW * s + rlane];
+                    zo_pf = C.zero_off[rlane];
+                }
+                unsigned long long pl_pf[BS], pj_pf[BS];
+                if constexpr (PFSITE(2)) {
+#pragma unroll
+                    for (int t = 0; t < BS; ++t) { const int bq = vb[t] < nb ? vb[t] : 0; pl_pf[t] = PLIST(t, bq); pj_pf[t] = JLIST(t, bq); }
+                }
+                double vown[LS];
+                {   // the partner's g of every slot in one batch of loads (the all-zero record when there is none) instead of one LDS round trip per
+                    // owner slot, each in a branch of its own (round 3: -1.7 % / -2.3 % kernel time on RTS-24 / RTS-96, bit-identical)
+                    double gp[LS];
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) gp[s] = LR[4 * (lpart[s] >= 0 ? lpart[s] : nlp)];
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) vown[s] = (((linfo[s] >> 24) & LF_OWNER) && !L_PIN(s)) ? -(gown[s] + gp[s]) : 0.0;
                 }
                 double d00[BS], d11[BS], r0[BS], r1[BS];
 #pragma unroll
@@ -872,7 +922,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         double md = 0.0, lx = 0.0, nq_ = 0.0, bal = 0.0, E = 0.0, ssum = 0.0;
                         // incidence lists come packed (one 8-byte LDS read each); unused slots point at the zero
                         // records, so all record loads of a bus are independent and issue back to back
-                        const unsigned long long pl = PLIST(t, bi), pj = JLIST(t, bi);
+                        const unsigned long long pl = PFSITE(2) ? pl_pf[t] : PLIST(t, bi), pj = PFSITE(2) ? pj_pf[t] : JLIST(t, bi);
                         // two list entries per step: their four (three) record loads issue together and one wait covers both;
                         // an odd list's last step reads the all-zero record once more (adds exact zeros)
 #pragma unroll
@@ -954,10 +1004,17 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         // block (hi, lo): rows of the later-eliminated bus, columns of the earlier one
                         const double c1 = L_C1Z(s) ? 0.0 : cBv[s];   // K[th_hi][lam_lo] = B(row lam_lo, col th_hi)
                         const double c2 = L_C2Z(s) ? 0.0 : cBv[s];   // K[lam_hi][th_lo] = B(row lam_hi, col th_lo)
-                        double* blk = W + C.l_blk[RW * s + rlane];
+                        double* blk = W + (PFSITE(1) ? lblk_pf[s] : (uint32_t)C.l_blk[RW * s + rlane]);
                         st2(blk, vown[s], c1); st2(blk + 2, c2, 0.0);
                     }
                 }
+                if constexpr (PFSITE(1)) {
+                    for (int z = rlane; z < nzero; z += RW) {
+                        const uint32_t zn = C.zero_off[z + RW < TL::MAXOFF ? z + RW : z];      // the next offset is on its way while this block is cleared
+                        double* blk = W + zo_pf; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0);
+                        zo_pf = zn;
+                    }
+                } else
                 for (int z = rlane; z < nzero; z += RW) { double* blk = W + C.zero_off[z]; st2(blk, 0.0, 0.0); st2(blk + 2, 0.0, 0.0); }
 #pragma unroll
                 for (int t = 0; t < BS; ++t) {
@@ -974,9 +1031,12 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 // The four conditions must hold together, so the two that need only |x| (complementarity and
                 // cost change) are tested first; the other three row reductions run only when some scenario
                 // of the wavefront passes them (never before the last 2-3 iterations).
+                double o_ct = 0.0, o_cc = 0.0, o_am = 0.0;
+                if constexpr (PFSITE(7)) { o_ct = A_(2, comptol); o_cc = A_(3, costtol); o_am = A_(7, alpha_min); }
                 mx_x = row_max<RW>(mx_x);
                 const bool xnan = row_any<RW>(nanx, lane);
-                bool conv = it > 0 && zmu < A_(2, comptol) * (1.0 + mx_x) && __builtin_fabs(fval - f0) < A_(3, costtol) * (1.0 + __builtin_fabs(f0));
+                if constexpr (!PFSITE(7)) { o_ct = A_(2, comptol); o_cc = A_(3, costtol); }
+                bool conv = it > 0 && zmu < o_ct * (1.0 + mx_x) && __builtin_fabs(fval - f0) < o_cc * (1.0 + __builtin_fabs(f0));
 #ifdef RELMC_TRACE
                 {   // debug builds: per-iteration termination quantities of scenario 0 (first launch row) -> a.timing as doubles
                     const double t_gh = row_max<RW>(mx_gh), t_z = row_max<RW>(mx_z), t_lx = row_max<RW>(mx_lx), t_lm = row_max<RW>(mx_lammu);
@@ -997,7 +1057,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 (void)conv; (void)xnan;
 #else
                 if (conv) { status = 0; iterating = false; }
-                else if (it > 0 && (xnan || alphap < A_(7, alpha_min) || alphad < A_(7, alpha_min) || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
+                else if (it > 0 && (xnan || alphap < (PFSITE(7) ? o_am : A_(7, alpha_min)) || alphad < (PFSITE(7) ? o_am : A_(7, alpha_min)) || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
 #endif
             }
@@ -1172,14 +1232,30 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 // (1e-10) then carries a relative error of 1e-6 and 1 % of the scenarios never converge; -h - z - dh keeps small with small.
                 double tp = 0.0, td = 0.0;        // max over inequality rows of -dz/z and -dmu/mu
                 double dF[LS], dG[LS];
+                double dpv[IS];
+                double o_ms = 0.0;
+                if constexpr (PFSITE(6)) o_ms = A_(8, max_stepsize);
+                if constexpr (PFSITE(3)) {
+                    d2 xf[LS], xt[LS], sh[IS]; double dlb[IS];
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) { xf[s] = ld2(X + 2 * (linfo[s] & 0xff)); xt[s] = ld2(X + 2 * ((linfo[s] >> 8) & 0xff)); }
+#pragma unroll
+                    for (int s = 0; s < IS; ++s) { dlb[s] = X[2 * (iinfo[s] & 0xff) + 1]; sh[s] = ld2(Stash + 2 * RW * s); }
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) { dF[s] = L_ON(s) ? lb(s) * (xf[s].x - xt[s].x) : 0.0; dG[s] = L_ON(s) ? lb(s) * (xf[s].y - xt[s].y) : 0.0; }
+#pragma unroll
+                    for (int s = 0; s < IS; ++s) dpv[s] = I_BOX(s) ? __builtin_fma(dlb[s], sh[s].x, -sh[s].y) : 0.0;
+                }
 #pragma unroll
                 for (int s = 0; s < LS; ++s) {
-                    dF[s] = 0; dG[s] = 0;
+                    if constexpr (!PFSITE(3)) { dF[s] = 0; dG[s] = 0; }
                     if (L_ON(s)) {
+                        if constexpr (!PFSITE(3)) {
                         const int f = linfo[s] & 0xff, t = (linfo[s] >> 8) & 0xff;
                         const d2 xf = ld2(X + 2 * f), xt = ld2(X + 2 * t);
                         dF[s] = lb(s) * (xf.x - xt.x);
                         dG[s] = lb(s) * (xf.y - xt.y);
+                        }
                         if (L_ACT(s)) {
                             const double hp = LFv[s] - lr(s), hm = -LFv[s] - lr(s);
                             const double dzp = -hp - lzp[s] - dF[s], dzm = -hm - lzm[s] + dF[s];
@@ -1192,19 +1268,24 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                         }
                     }
-                    SLOT_FENCE();
+                    SLOT_FENCE_AT(2);
                 }
-                double dpv[IS];
+                d2 rt_hl = d2{0.0, 0.0};
+                if constexpr (PFSITE(4)) rt_hl = IHL(0, rlane);
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
-                    dpv[s] = 0;
+                    if constexpr (!PFSITE(3)) dpv[s] = 0;
+                    const d2 hl_pf = rt_hl;
+                    if constexpr (PFSITE(4)) if (s + 1 < IS) rt_hl = IHL(s + 1, RW * (s + 1) + rlane);
                     {
                         if (I_BOX(s)) {
+                            if constexpr (!PFSITE(3)) {
                             const double dlb = X[2 * (iinfo[s] & 0xff) + 1];
                             const d2 sh = ld2(Stash + 2 * RW * s);
                             dpv[s] = __builtin_fma(dlb, sh.x, -sh.y);   // dp = (-Np + dlam)/D
-                            const d2 hl = IHL(s, j);
+                            }
+                            const d2 hl = PFSITE(4) ? hl_pf : IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             double rzp, rzm; frcp_pair<PAIRSITE(4)>(izp[s], izm[s], rzp, rzm);
@@ -1216,7 +1297,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
-                    SLOT_FENCE();
+                    SLOT_FENCE_AT(3);
                 }
                 step2 = row_sum<RW>(step2);
 #ifdef RELMC_TRACE
@@ -1230,14 +1311,19 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #ifdef RELMC_ABLATE_FIXIT
                 if (false) {
 #else
-                if (!(step2 <= A_(8, max_stepsize) * A_(8, max_stepsize))) {
+                if (!(PFSITE(6) ? step2 <= o_ms * o_ms : step2 <= A_(8, max_stepsize) * A_(8, max_stepsize))) {
 #endif
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
+                    double o_xi = 0.0, o_sg = 0.0;
+                    d2 up_hl = d2{0.0, 0.0}; double up_co = 0.0;
+                    if constexpr (PFSITE(6)) { o_xi = A_(4, xi); o_sg = A_(5, sigma); }
+                    if constexpr (PFSITE(5)) { up_hl = IHL(0, rlane); up_co = ICOST(0, rlane); }
                     tp = row_max<RW>(tp); td = row_max<RW>(td);
-                    alphap = tp > 0.0 ? vmin(A_(4, xi) * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
-                    alphad = td > 0.0 ? vmin(A_(4, xi) * frcp(td), 1.0) : 1.0;
+                    if constexpr (!PFSITE(6)) o_xi = A_(4, xi);
+                    alphap = tp > 0.0 ? vmin(o_xi * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
+                    alphad = td > 0.0 ? vmin(o_xi * frcp(td), 1.0) : 1.0;
                     double zl = 0.0, fl = 0.0;
 #pragma unroll
                     for (int s = 0; s < LS; ++s) {
@@ -1253,13 +1339,15 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         }
                         LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);      // dF = dG = 0 on a line out of service
                         LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
-                        SLOT_FENCE();
+                        SLOT_FENCE_AT(4);
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
+                        const d2 hl_pf = up_hl; const double co_pf = up_co;
+                        if constexpr (PFSITE(5)) if (s + 1 < IS) { up_hl = IHL(s + 1, RW * (s + 1) + rlane); up_co = ICOST(s + 1, RW * (s + 1) + rlane); }
                         if (I_BOX(s)) {
                             const int j = RW * s + rlane;
-                            const d2 hl = IHL(s, j);
+                            const d2 hl = PFSITE(5) ? hl_pf : IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             double rzp, rzm; frcp_pair<PAIRSITE(7)>(izp[s], izm[s], rzp, rzm);
@@ -1270,8 +1358,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
                             zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                         }
-                        fl = __builtin_fma(ICOST(s, RW * s + rlane), ip[s], fl);      // p = 0 on an injection out of service
-                        SLOT_FENCE();
+                        fl = __builtin_fma(PFSITE(5) ? co_pf : ICOST(s, RW * s + rlane), ip[s], fl);      // p = 0 on an injection out of service
+                        SLOT_FENCE_AT(5);
                     }
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
@@ -1280,7 +1368,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     zmu = row_sum<RW>(zl);
                     fval = row_sum<RW>(fl);
-                    if (niq > 0) gamma = A_(5, sigma) * zmu / (double)niq;
+                    if (niq > 0) gamma = (PFSITE(6) ? o_sg : A_(5, sigma)) * zmu / (double)niq;
                 }
                 PT_MARK(6)
             }
