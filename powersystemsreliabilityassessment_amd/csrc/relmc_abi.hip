@@ -299,7 +299,7 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
     C.off_rhs = (uint16_t)(4 * (nb + noff));          // rhs / solution: 2 doubles per bus
     C.off_p = 0;                                        // P = inv(D) overwrites D in place
     C.nws = (uint32_t)C.off_rhs + 2u * nb;
-    if (C.nws >= 0x8000u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver workspace too large");
+    if (C.nws >= 0x1000u) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_case_load: solver workspace too large");      // byte offsets of the pass descriptors keep bit 15 free
     auto OFFD = [&](int i) { return 4 * i; };
     std::vector<int> pos(nb + noff);                    // block id -> position in W (diagonal blocks stay at their bus index)
     for (int k = 0; k < nb + noff; ++k) pos[k] = k;
@@ -502,6 +502,9 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
                 return o | f;
             };
             // operand reads of a task: (offset index into t.o, +2 doubles?) per kind; rhs-row tasks skip the second halves of T and Wa
+            // operands that are written back (T; D and y of an inversion; y_i of a back substitution) hit the same banks a second time with the
+            // slower store instruction: their conflicts can be given more weight (RELMC_PLACE_WW, default 1 = reads only, as measured so far)
+            const long ww = getenv("RELMC_PLACE_WW") ? atol(getenv("RELMC_PLACE_WW")) : 1;
             auto pass_cost = [&](int p) {
                 long cost = 0;
                 const int kind = pkind[p];
@@ -539,7 +542,8 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
                         for (int k = 0; k < cnt[g][q]; ++k) if (addr[g][q][k] == ad) { seen = true; break; }
                         if (!seen) addr[g][q][cnt[g][q]++] = ad;
                     }
-                    for (int g = 0; g < 4; ++g) { int mx = 0; for (int q = 0; q < 16; ++q) if (cnt[g][q] > mx) mx = cnt[g][q]; if (mx > 1) cost += mx - 1; }
+                    const bool written = kind == 0 ? (ins == 5 || ins == 7) : (kind == 1 ? true : ins == 5);
+                    for (int g = 0; g < 4; ++g) { int mx = 0; for (int q = 0; q < 16; ++q) if (cnt[g][q] > mx) mx = cnt[g][q]; if (mx > 1) cost += (mx - 1) * (written ? ww : 1); }
                 }
                 return cost;
             };
@@ -633,6 +637,21 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
                     }
                 }
             }
+        }
+        // The kernel adds a descriptor field to the workspace's LDS address as it is (one VALU instruction per operand instead of two): the
+        // table holds BYTE offsets (< 32 KiB: a scenario's workspace is a fraction of the 160 KiB of LDS), bit 15 of field 0 = rhs task as before.
+        {
+            int nup_all = 0;
+            for (size_t q = 0; q < pkind.size(); ++q) if (pkind[q] == 0) nup_all++;
+            const int nfull_upd = nup_all - (int)C.npass_updq - (int)C.npass_updh;          // only the full-form update passes carry the rhs flag
+            for (size_t q = 0; q < pkind.size(); ++q)
+                for (int r = 0; r < ROWL; ++r) {
+                    if (C.task[q][r][0] == 0xffff) continue;
+                    for (int k = 0; k < 4; ++k) {
+                        const uint32_t v = C.task[q][r][k], f = (k == 0 && (int)q < nfull_upd) ? (v & 0x8000u) : 0u;
+                        C.task[q][r][k] = (uint16_t)(((v & (f ? 0x7fffu : 0xffffu)) << 3) | f);
+                    }
+                }
         }
         C.npass = (uint16_t)pkind.size();
         int nu = 0, ni = 0;
@@ -2584,7 +2603,12 @@ int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, in
         hdr[8] = C.npass_inv; hdr[9] = C.npass_updh; hdr[10] = C.npass_updq; hdr[11] = C.nzero; hdr[12] = (int)g.scen_doubles; hdr[13] = (int)g.lds_bytes;
         hdr[14] = (int)g.conflict_before; hdr[15] = (int)g.conflict_after; hdr[16] = maxpass; hdr[17] = C.nl;
         if ((int64_t)C.npass * rw * 4 > tasks_cap) return (int)RELMC_ERR_INVALID;
-        for (int p = 0; p < C.npass; ++p) { pass_ntask[p] = C.pass_ntask[p]; for (int r = 0; r < rw; ++r) for (int k = 0; k < 4; ++k) tasks[((size_t)p * rw + r) * 4 + k] = C.task[p][r][k]; }
+        for (int p = 0; p < C.npass; ++p) { pass_ntask[p] = C.pass_ntask[p]; for (int r = 0; r < rw; ++r) for (int k = 0; k < 4; ++k) {
+            // back to offsets in doubles (what tests/schedule_interp.py executes); bit 15 of field 0 of a full-form update pass is the rhs flag
+            const uint16_t v = C.task[p][r][k];
+            const bool full_upd = p < C.npass_upd - C.npass_updh - C.npass_updq;
+            tasks[((size_t)p * rw + r) * 4 + k] = C.task[p][r][0] == 0xffff ? v : (uint16_t)((k == 0 && full_upd) ? (((v & 0x7fffu) >> 3) | (v & 0x8000u)) : (v >> 3));
+        } }
         for (int i = 0; i < C.nb; ++i) b_int[i] = C.b_int[i];
         for (int l = 0; l < C.nl; ++l) { l_info[l] = C.l_info[l]; l_blk[l] = ((C.l_info[l] >> 24) & LF_OWNER) ? C.l_blk[l] : (uint16_t)0xffff; }
         for (int z = 0; z < C.nzero; ++z) zero_off[z] = C.zero_off[z];

@@ -1111,23 +1111,39 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
 #ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
                 // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
+                // descriptor fields are byte offsets into the scenario's workspace (bit 15 of the first = rhs task in the full-form passes)
+                unsigned char* const W8 = reinterpret_cast<unsigned char*>(W);
+#define WP(off) reinterpret_cast<double*>(W8 + (off))
                 uint2 dsc = *reinterpret_cast<const uint2*>(&TASKSRC.task[0][rlane][0]);
                 for (int p = 0; p < npuf; ++p) {             // T -= Wa * inv(D) * Wb'   (T: 2x2 block, or 1x2 rhs row)
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
                         const bool vec = (dsc.x & 0x8000u) != 0;            // rhs pseudo-bus: Wa = [y_i'; 0], T = y_a'
-                        double* T = W + (dsc.x & 0x7fffu);
-                        const double* Wa = W + (dsc.x >> 16);
-                        const double* Wb = W + (dsc.y & 0xffffu);
-                        const double* D = W + (dsc.y >> 16);
+                        double* T = WP(dsc.x & 0x7fffu);
+                        const double* Wa = WP(dsc.x >> 16);
+                        const double* Wb = WP(dsc.y & 0xffffu);
+                        const double* D = WP(dsc.y >> 16);
                         const d2 dA = ld2(D); const double dBy = D[3];      // D = [[m, b], [b, -e]]: the second half is needed for -e only (b64 read)
                         const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
                         d2 t0 = ld2(T);
+#ifdef RELMC_UPD_ONE_BATCH
+                        // A/B (round 3): all eight operand loads in one batch instead of the second rows after the first row's store -- one LDS round
+                        // trip less per full-form pass, and 0.7 % / 1.5 % SLOWER on RTS-24 / RTS-96 (profiles/r3_pf/c17_*.log): these passes are bound
+                        // by the LDS pipe, not by its latency, and the longer batch holds the pipe against the other wavefronts of the CU.
+                        const d2 a1 = ld2(Wa + 2);
+                        d2 t1 = ld2(T + 2);
+#endif
                         const double pm = dA.x, pb = dA.y, pe = -dBy;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
                         const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
                         t0.x -= __builtin_fma(g00, b0.x, g01 * b0.y); t0.y -= __builtin_fma(g00, b1.x, g01 * b1.y);
+#ifdef RELMC_UPD_ONE_BATCH
+                        const double g10 = __builtin_fma(a1.x, P00, a1.y * P01), g11 = __builtin_fma(a1.x, P01, a1.y * P11);
+                        t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
+                        st2(T, t0.x, t0.y);
+                        if (!vec) st2(T + 2, t1.x, t1.y);
+#else
                         st2(T, t0.x, t0.y);
                         if (!vec) {
                             const d2 a1 = ld2(Wa + 2);
@@ -1136,16 +1152,17 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
                             st2(T + 2, t1.x, t1.y);
                         }
+#endif
                     }
                     dsc = nxt;
                 }
                 for (int p = npuf; p < npuh; ++p) {          // the same update, one row of T per lane (passes filled to at most a half, relmc_dev.h)
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
-                        double* T = W + (dsc.x & 0xffffu);
-                        const double* Wa = W + (dsc.x >> 16);
-                        const double* Wb = W + (dsc.y & 0xffffu);
-                        const double* D = W + (dsc.y >> 16);
+                        double* T = WP(dsc.x & 0xffffu);
+                        const double* Wa = WP(dsc.x >> 16);
+                        const double* Wb = WP(dsc.y & 0xffffu);
+                        const double* D = WP(dsc.y >> 16);
                         const d2 dA = ld2(D); const double dBy = D[3];
                         const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
                         d2 t0 = ld2(T);
@@ -1161,10 +1178,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int p = npuh; p < npu; ++p) {           // the same update, one element of T per lane (sparsely filled passes, relmc_dev.h)
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
-                        double* T = W + (dsc.x & 0xffffu);
-                        const double* Wa = W + (dsc.x >> 16);
-                        const double* Wb = W + (dsc.y & 0xffffu);
-                        const double* D = W + (dsc.y >> 16);
+                        double* T = WP(dsc.x & 0xffffu);
+                        const double* Wa = WP(dsc.x >> 16);
+                        const double* Wb = WP(dsc.y & 0xffffu);
+                        const double* D = WP(dsc.y >> 16);
                         const d2 dA = ld2(D); const double dBy = D[3];
                         const d2 a0 = ld2(Wa), b0 = ld2(Wb);
                         double t = *T;
@@ -1181,8 +1198,8 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int p = npu; p < npu + npi; ++p) {      // D <- P = inv(D) in place; y <- P*y
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
-                        double* D = W + (dsc.x & 0xffffu);
-                        double* Y = W + (dsc.x >> 16);
+                        double* D = WP(dsc.x & 0xffffu);
+                        double* Y = WP(dsc.x >> 16);
                         const d2 dA = ld2(D), y = ld2(Y); const double dBy = D[3];
                         const double pm = dA.x, pb = dA.y, pe = -dBy;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
@@ -1196,10 +1213,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                 for (int p = npu + npi; p < npass; ++p) {    // y_i -= P_i * W' * x_a
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {
-                        double* Yi = W + (dsc.x & 0xffffu);
-                        const double* Wk = W + (dsc.x >> 16);
-                        const double* P = W + (dsc.y & 0xffffu);
-                        const double* Ya = W + (dsc.y >> 16);
+                        double* Yi = WP(dsc.x & 0xffffu);
+                        const double* Wk = WP(dsc.x >> 16);
+                        const double* P = WP(dsc.y & 0xffffu);
+                        const double* Ya = WP(dsc.y >> 16);
                         const d2 w0 = ld2(Wk), w1 = ld2(Wk + 2), p0 = ld2(P), p1 = ld2(P + 2), x = ld2(Ya);
                         d2 y = ld2(Yi);
                         const double u0 = __builtin_fma(w0.x, x.x, w1.x * x.y), u1 = __builtin_fma(w0.y, x.x, w1.y * x.y);
