@@ -195,7 +195,7 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 //   2 gathers: incidence lists of both bus slots up front              3 step: the lines' and injections' solution entries as one batch
 //   4 / 5 ratio tests / update: injection bounds (and cost) one slot ahead    6 / 7 step / convergence test: solver options requested before the row reductions
 #ifndef RELMC_PF_MASK
-#define RELMC_PF_MASK 0xc8          // 16-lane tile: sites 3, 6, 7 (-1.4 % kernel time; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
+#define RELMC_PF_MASK 0xc0          // 16-lane tile: sites 6, 7 (-1 % kernel time; site 3 on top: -0.3 % for +44 B/lane of scratch = +40 % HBM traffic, not taken; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
 #endif
 #ifndef RELMC_PF_MASK_WIDE
 #define RELMC_PF_MASK_WIDE 0xc6     // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
@@ -1256,10 +1256,17 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     d2 xf[LS], xt[LS], sh[IS]; double dlb[IS];
 #pragma unroll
                     for (int s = 0; s < LS; ++s) { xf[s] = ld2(X + 2 * (linfo[s] & 0xff)); xt[s] = ld2(X + 2 * ((linfo[s] >> 8) & 0xff)); }
-#pragma unroll
-                    for (int s = 0; s < IS; ++s) { dlb[s] = X[2 * (iinfo[s] & 0xff) + 1]; sh[s] = ld2(Stash + 2 * RW * s); }
+#ifdef RELMC_PF3_SPLIT       // A/B: two batches (lines, then injections) instead of one: fewer values in flight
 #pragma unroll
                     for (int s = 0; s < LS; ++s) { dF[s] = L_ON(s) ? lb(s) * (xf[s].x - xt[s].x) : 0.0; dG[s] = L_ON(s) ? lb(s) * (xf[s].y - xt[s].y) : 0.0; }
+                    SLOT_FENCE();
+#endif
+#pragma unroll
+                    for (int s = 0; s < IS; ++s) { dlb[s] = X[2 * (iinfo[s] & 0xff) + 1]; sh[s] = ld2(Stash + 2 * RW * s); }
+#ifndef RELMC_PF3_SPLIT
+#pragma unroll
+                    for (int s = 0; s < LS; ++s) { dF[s] = L_ON(s) ? lb(s) * (xf[s].x - xt[s].x) : 0.0; dG[s] = L_ON(s) ? lb(s) * (xf[s].y - xt[s].y) : 0.0; }
+#endif
 #pragma unroll
                     for (int s = 0; s < IS; ++s) dpv[s] = I_BOX(s) ? __builtin_fma(dlb[s], sh[s].x, -sh[s].y) : 0.0;
                 }
