@@ -791,6 +791,7 @@ int case_load_impl(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, in
 {
     const bool alt = order_variant != 0;            // the alternate image: geometry into the alt_* fields, nothing else of the context changes
     constexpr int WPB = TL::WPB;
+    if (getenv("RELMC_MODEL_LEAF_FREE")) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: RELMC_MODEL_LEAF_FREE is a scheduling model for relmc_debug_symbolic only (its pass program is incomplete)");
     SymGeom geom;
     {
         const int rc = case_symbolic<TL>(ctx, d, C, order_variant, geom);

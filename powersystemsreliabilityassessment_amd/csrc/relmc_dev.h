@@ -48,7 +48,7 @@ constexpr uint32_t IK_NONE = 0u, IK_REAL = 1u, IK_VIRTUAL = 2u;
 // instructions per pass instead of ten, which is what a pass costs whatever its fill.  Quarter descriptor = (&T[r][c], &Wa[r][0], &Wb[c][0], D).
 // In front of them, npass_updh passes of at most RW / 2 tasks in HALF form: two lanes per task, lane r updating the row T[r][:] (seven LDS
 // instructions).  Half descriptor = (&T[r][0], &Wa[r][0], Wb, D).
-//   PK_UPD  T -= Wa * inv(D) * Wb'         task = (T, Wa, Wb, D)      W offsets of 2x2 blocks
+//   PK_UPD  T -= Wa * inv(D) * Wb'         task = (T, Wa, Wb, D)      BYTE offsets into W of 2x2 blocks (bit 15 of T = rhs task; full form only)
 //   PK_INV  P = inv(D); y <- P * y         task = (D, Y, P, -)
 //   PK_BWD  y_i -= P_i * W' * x_a          task = (Y_i, W, P_i, Y_a)
 //
@@ -97,7 +97,7 @@ struct DevCaseT {
     // static schedule of the sparse block LDL' (computed once per case on the host)
     uint16_t zero_off[MAXOFF];      // W offsets of fill-only blocks (cleared every iteration)
     uint8_t pass_ntask[MAXPASS];
-    uint16_t task[MAXPASS][ROWL][4];
+    uint16_t task[MAXPASS][ROWL][4];    // byte offsets into the scenario's workspace (< 32 KiB), 0xffff in field 0 = no task for this lane
 };
 
 // per-lane partial accumulators written once per workgroup-row, reduced by relmc_finalize_kernel
