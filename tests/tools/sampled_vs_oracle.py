@@ -1,0 +1,31 @@
+"""The contract of the shipped arithmetic on SAMPLED states (not only the fixtures): the first N samples of seed 1, device against the C oracle,
+both policies -- status, dns, iteration counts, per-bus nodal sums.  Developer tool, needs a GPU and the oracle (CPU: N / 43 k per second)."""
+import os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
+import numpy as np
+from powersystemsreliabilityassessment_amd import api, case24, case96
+from oracle import coracle
+N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
+which = sys.argv[2] if len(sys.argv) > 2 else "rts24"
+c = case24.rts24() if which == "rts24" else case96.rts96()
+eng = api.Engine(c); orc = coracle.Oracle(c)
+CH = 250_000
+for name, pol in (("emulate", 0), ("physical", 1)):
+    tot = dict(n=0, status=0, dns6=0, it1=0, it2=0, nc_dev=0, nc_orc=0); maxd = 0.0
+    nod_d = np.zeros(c.nb); nod_o = np.zeros(c.nb); sd = so = 0.0; t = time.time()
+    for lo in range(0, N, CH):
+        n = min(CH, N - lo)
+        st = eng.mc_sampling(None, n, seed=1, first_index=lo)
+        dns, nodal, info = eng.mc_simulation(st, mpopt=api.mpoption(pol), return_info=True)
+        r = orc.mc_simulation(st, pol, nthreads=16)
+        ok = (info["status"] == r["status"])
+        both = ok & (r["status"] == 0)
+        dd = np.abs(dns - r["dns"]); di = np.abs(info["iters"] - r["iters"])
+        tot["n"] += n; tot["status"] += int((~ok).sum()); tot["dns6"] += int((dd[ok] > 1e-6).sum()); maxd = max(maxd, float(dd[ok].max()))
+        tot["it1"] += int((di[both] == 1).sum()); tot["it2"] += int((di[both] > 1).sum())
+        tot["nc_dev"] += int(np.isin(info["status"], (1, 2)).sum()); tot["nc_orc"] += int(np.isin(r["status"], (1, 2)).sum())
+        nod_d += nodal.sum(0); nod_o += r["nodal"].sum(0); sd += dns.sum(); so += r["dns"].sum()
+    m = nod_o > 0
+    print("%s %s: %d sampled states in %.0f s: status differs %d, |ddns| > 1e-6 MW %d (max %.2e), iterations +-1 %d (%.4f %%), beyond %d; non-converged device %d / oracle %d; "
+          "sum dns rel diff %.2e; per-bus nodal sums rel diff max %.2e" % (which, name, tot["n"], time.time() - t, tot["status"], tot["dns6"], maxd, tot["it1"], 100.0 * tot["it1"] / tot["n"],
+          tot["it2"], tot["nc_dev"], tot["nc_orc"], abs(sd - so) / so, (np.abs(nod_d[m] - nod_o[m]) / nod_o[m]).max()), flush=True)
