@@ -638,6 +638,28 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
                 }
             }
         }
+        // back-substitution passes filled to at most a half in half form (relmc_dev.h): one LDS instruction less per pass
+        C.bwd_half = 0;
+        if (!getenv("RELMC_NO_BWD_HALF")) {
+            int first_bwd = 0;
+            while (first_bwd < (int)pkind.size() && pkind[first_bwd] != 2) first_bwd++;
+            // all or nothing: a loop that switches form per pass costs more than the half form saves (measured: +1.6 % / +2.5 % against the
+            // full form alone, profiles/r3_pf/c26_notes.txt), so the half form is taken when EVERY pass qualifies (RTS-96: 11 of 11; RTS-24: 5 of 7, stays full)
+            // The 16-lane tile keeps the full form: its kernel is 0.35 % slower with the second loop compiled in, whatever runs.
+            bool all_half = ROWL == 64 && (int)pkind.size() - first_bwd <= 64 && first_bwd < (int)pkind.size();
+            for (int p = first_bwd; p < (int)pkind.size(); ++p) if (pcount[p] > ROWL / 2) all_half = false;
+            for (int p = first_bwd; all_half && p < (int)pkind.size(); ++p) {
+                uint16_t full[ROWL][4]; int nfull = 0;
+                for (int r = 0; r < ROWL; ++r) if (C.task[p][r][0] != 0xffff) { for (int k = 0; k < 4; ++k) full[nfull][k] = C.task[p][r][k]; nfull++; }
+                for (int r = 0; r < ROWL; ++r) for (int k = 0; k < 4; ++k) C.task[p][r][k] = 0xffff;
+                for (int t = 0; t < nfull; ++t)
+                    for (int r = 0; r < 2; ++r) {
+                        uint16_t* q = C.task[p][2 * t + r];
+                        q[0] = (uint16_t)(full[t][0] + r); q[1] = full[t][1]; q[2] = (uint16_t)(full[t][2] + 2 * r); q[3] = full[t][3];
+                    }
+                C.bwd_half |= 1ull << (p - first_bwd);
+            }
+        }
         // The kernel adds a descriptor field to the workspace's LDS address as it is (one VALU instruction per operand instead of two): the
         // table holds BYTE offsets (< 32 KiB: a scenario's workspace is a fraction of the 160 KiB of LDS), bit 15 of field 0 = rhs task as before.
         {
@@ -2603,6 +2625,7 @@ int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, in
         hdr[0] = tile; hdr[1] = rw; hdr[2] = C.nb; hdr[3] = C.noff; hdr[4] = (int)C.nws; hdr[5] = C.off_rhs; hdr[6] = C.npass; hdr[7] = C.npass_upd;
         hdr[8] = C.npass_inv; hdr[9] = C.npass_updh; hdr[10] = C.npass_updq; hdr[11] = C.nzero; hdr[12] = (int)g.scen_doubles; hdr[13] = (int)g.lds_bytes;
         hdr[14] = (int)g.conflict_before; hdr[15] = (int)g.conflict_after; hdr[16] = maxpass; hdr[17] = C.nl;
+        hdr[19] = (int32_t)(uint32_t)(C.bwd_half & 0xffffffffull); hdr[20] = (int32_t)(uint32_t)(C.bwd_half >> 32);
         if ((int64_t)C.npass * rw * 4 > tasks_cap) return (int)RELMC_ERR_INVALID;
         for (int p = 0; p < C.npass; ++p) { pass_ntask[p] = C.pass_ntask[p]; for (int r = 0; r < rw; ++r) for (int k = 0; k < 4; ++k) {
             // back to offsets in doubles (what tests/schedule_interp.py executes); bit 15 of field 0 of a full-form update pass is the rhs flag

@@ -51,6 +51,8 @@ constexpr uint32_t IK_NONE = 0u, IK_REAL = 1u, IK_VIRTUAL = 2u;
 //   PK_UPD  T -= Wa * inv(D) * Wb'         task = (T, Wa, Wb, D)      BYTE offsets into W of 2x2 blocks (bit 15 of T = rhs task; full form only)
 //   PK_INV  P = inv(D); y <- P * y         task = (D, Y, P, -)
 //   PK_BWD  y_i -= P_i * W' * x_a          task = (Y_i, W, P_i, Y_a)
+//           half form (a pass of at most RW / 2 tasks): two lanes per task, lane r updating y_i[r] -= P_i[r][:] . (W' x_a) -- six LDS instructions
+//           instead of seven.  Half descriptor = (&Y_i[r], W, &P_i[r][0], Y_a).
 //
 // Per-scenario solver workspace W (doubles), 2x2 blocks row-major [tt, tl, lt, ll]:
 //   [0, 4*nb)                 diagonal blocks  D_i = [[M_ii, B_ii], [B_ii, -E_i]]
@@ -69,6 +71,7 @@ struct DevCaseT {
     uint16_t maxdeg, maxinj, base_connected, npass_updq;   // npass_updq: the last PK_UPD passes in quarter form (below)   // base_connected: the network with every line in service is one island   // largest number of lines / injections at one bus
     uint16_t maxdeg_s[2], maxinj_s[2];   // longest line / injection list among the buses of bus slot 0 / 1
     uint16_t npass_updh, pad3[3];   // PK_UPD passes in half form, in front of the quarter-form ones
+    uint64_t bwd_half;              // bit k: PK_BWD pass k (counted from the first one) is in half form; all of them or none (relmc_case_load)
     uint64_t b_line8[NBT];          // the bus' line list packed one byte each (id | 0x80 = 'to' end), unused entries = nl (the all-zero record)
     uint64_t b_inj8[NBT];           // the bus' injection list packed one byte each, unused entries = ninj (the all-zero record)
     // lines

@@ -288,6 +288,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     uint32_t* const OB = reinterpret_cast<uint32_t*>(Lam + NBT);   // [OW]: outage mask of the scenario
 
     const int ng = C.ng, ncomp = C.ncomp, nb = C.nb;
+    const bool bwd_all_half = __builtin_amdgcn_readfirstlane((uint32_t)(C.bwd_half != 0 ? 1u : 0u)) != 0;      // all back-substitution passes in half form (relmc_dev.h)
     const int off_rhs = C.off_rhs, npu = C.npass_upd, npi = C.npass_inv, npass = C.npass, nzero = C.nzero, npuh = C.npass_upd - C.npass_updq, npuf = npuh - C.npass_updh;
     const double base = C.base_mva;
     const double eps = 2.220446049250313e-16;
@@ -1210,6 +1211,23 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     dsc = nxt;
                 }
                 PT_MARK(5)
+                if (RW == 64 && bwd_all_half) {               // every back-substitution pass is filled to at most a half: one component of y_i per lane (wide tile only)
+                    for (int p = npu + npi; p < npass; ++p) {
+                        const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
+                        if ((dsc.x & 0xffffu) != 0xffffu) {
+                            double* Yi = WP(dsc.x & 0xffffu);
+                            const double* Wk = WP(dsc.x >> 16);
+                            const double* Pr = WP(dsc.y & 0xffffu);
+                            const double* Ya = WP(dsc.y >> 16);
+                            const d2 w0 = ld2(Wk), w1 = ld2(Wk + 2), pr = ld2(Pr), x = ld2(Ya);
+                            double y = *Yi;
+                            const double u0 = __builtin_fma(w0.x, x.x, w1.x * x.y), u1 = __builtin_fma(w0.y, x.x, w1.y * x.y);
+                            y -= __builtin_fma(pr.x, u0, pr.y * u1);
+                            *Yi = y;
+                        }
+                        dsc = nxt;
+                    }
+                } else
                 for (int p = npu + npi; p < npass; ++p) {    // y_i -= P_i * W' * x_a
                     const uint2 nxt = *reinterpret_cast<const uint2*>(&TASKSRC.task[p + 1][rlane][0]);
                     if ((dsc.x & 0xffffu) != 0xffffu) {

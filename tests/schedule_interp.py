@@ -4,7 +4,7 @@
 back the pass program the evaluation kernel interprets.  `solve()` executes that program with numpy on one bus-pair system
 [[M, B'], [B, -E]] in exactly the kernel's data layout (2x2 blocks in a flat workspace W, the right-hand side as a pseudo bus)
 and returns the solution, which the tests compare with numpy.linalg.solve on the dense matrix.  Every pass form is covered:
-full / half / quarter block updates, pivot inversion, back substitution.
+full / half / quarter block updates, pivot inversion, full / half back substitution.
 """
 from __future__ import annotations
 
@@ -38,6 +38,7 @@ class Schedule:
     conflict_after: int
     nl: int
     flags: int
+    bwd_half: int              # bit k: back-substitution pass k is in half form
     tasks: np.ndarray          # [npass, rw, 4] uint16
     pass_ntask: np.ndarray
     b_int: np.ndarray          # external -> internal bus
@@ -73,7 +74,7 @@ def symbolic(case, order_variant: int = 0) -> Schedule:
     npass, rw = h[6], h[1]
     return Schedule(tile=h[0], rw=rw, nb=h[2], noff=h[3], nws=h[4], off_rhs=h[5], npass=npass, npass_upd=h[7], npass_inv=h[8],
                     npass_updh=h[9], npass_updq=h[10], nzero=h[11], scen_doubles=h[12], lds_bytes=h[13], conflict_before=h[14],
-                    conflict_after=h[15], nl=h[17], flags=h[18],
+                    conflict_after=h[15], nl=h[17], flags=h[18], bwd_half=(h[19] & 0xffffffff) | ((h[20] & 0xffffffff) << 32),
                     tasks=tasks[: npass * rw * 4].reshape(npass, rw, 4).copy(), pass_ntask=pnt[:npass].copy(), b_int=b_int[: h[2]].copy(),
                     l_blk=l_blk[: h[17]].copy(), l_info=l_info[: h[17]].copy(), zero_off=zero_off[: h[11]].copy())
 
@@ -175,6 +176,12 @@ def solve(s: Schedule, W: np.ndarray) -> np.ndarray:
                 y = W[Y: Y + 2]
                 stores.append((D, np.array([P00, P01, P01, P11])))
                 stores.append((Y, np.array([P00 * y[0] + P01 * y[1], P01 * y[0] + P11 * y[1]])))
+            elif (s.bwd_half >> (p - npu - npi)) & 1:          # half form: one component of y_i per lane
+                Yi, Wk, Pr, Ya = d
+                w0, w1 = W[Wk: Wk + 2], W[Wk + 2: Wk + 4]
+                pr = W[Pr: Pr + 2]; x = W[Ya: Ya + 2]
+                u0, u1 = w0[0] * x[0] + w1[0] * x[1], w0[1] * x[0] + w1[1] * x[1]
+                stores.append((Yi, np.array([W[Yi] - (pr[0] * u0 + pr[1] * u1)])))
             else:                                              # y_i -= P_i W' x_a
                 Yi, Wk, P, Ya = d
                 w0, w1 = W[Wk: Wk + 2], W[Wk + 2: Wk + 4]
