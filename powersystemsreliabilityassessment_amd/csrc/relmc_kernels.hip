@@ -191,9 +191,10 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #endif
 // LDS round trips of the vector phases taken off the wavefront's critical path (RELMC_PF_MASK, bit k = site k): operands of the NEXT slot
 // are requested before the current slot is worked on, and loads that sat in separate branches are issued as one batch.  Same arithmetic.
-//   0 evaluation: injection bounds / cost / lambda one slot ahead      1 assembly: block offsets before the gathers
-//   2 gathers: incidence lists of both bus slots up front              3 step: the lines' and injections' solution entries as one batch
-//   4 / 5 ratio tests / update: injection bounds (and cost) one slot ahead    6 / 7 step / convergence test: solver options requested before the row reductions
+//   1 assembly: block offsets before the gathers                       2 gathers: incidence lists of both bus slots up front
+//   3 step: the lines' and injections' solution entries as one batch   6 / 7 step / convergence test: solver options requested before the row reductions
+// (sites 0, 4, 5 -- injection bounds / cost / lambda one slot ahead in the evaluation, the ratio tests, the update -- were measured neutral
+//  to +1.8 % on both tiles and are gone from the source: profiles/r3_pf/c13_*.log)
 #ifndef RELMC_PF_MASK
 #define RELMC_PF_MASK 0xc0          // 16-lane tile: sites 6, 7 (-1 % kernel time; site 3 on top: -0.3 % for +44 B/lane of scratch = +40 % HBM traffic, not taken; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
 #endif
@@ -853,8 +854,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (l < nlp) { st2(LR + 4 * l, g, lx); st2(LR + 4 * l + 2, lx + q, LFv[s]); }   // nl / ninj records (they alias W)
                     SLOT_FENCE_AT(0);
                 }
-                d2 ev_hl = d2{0.0, 0.0}; double ev_co = 0.0, ev_la = 0.0;
-                if constexpr (PFSITE(0)) { ev_hl = IHL(0, rlane); ev_co = ICOST(0, rlane); ev_la = Lam[iinfo[0] & 0xff]; }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
@@ -862,12 +861,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     const double pv = ip[s];         // stays 0 on an injection out of service
                     mx_x = vmax(mx_x, __builtin_fabs(pv));
                     nanx = nanx || pv != pv;
-                    const d2 hl_pf = ev_hl; const double co_pf = ev_co, la_pf = ev_la;
-                    if constexpr (PFSITE(0)) if (s + 1 < IS) { ev_hl = IHL(s + 1, RW * (s + 1) + rlane); ev_co = ICOST(s + 1, RW * (s + 1) + rlane); ev_la = Lam[iinfo[s + 1 < IS ? s + 1 : s] & 0xff]; }
                     if (I_BOX(s)) {
-                        const d2 hl = PFSITE(0) ? hl_pf : IHL(s, j);               // {upper, lower} bound
+                        const d2 hl = IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
-                        const double lxp = (PFSITE(0) ? co_pf : ICOST(s, j)) - (PFSITE(0) ? la_pf : Lam[iinfo[s] & 0xff]) + (imup[s] - imum[s]);
+                        const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
                         if constexpr (RW == 16 && RELMC_INJ_NFORM) {
                             // D = N / (z+ z-) with N = mu+ z- + mu- z+: 1/D and Np/D from ONE reciprocal (of N) instead of three (round 3: -1.9 %
                             // kernel time; no fixture state changes its iteration count, 6 of 1e6 sampled scenarios do by one).  The 64-lane tile keeps
@@ -1312,14 +1309,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     SLOT_FENCE_AT(2);
                 }
-                d2 rt_hl = d2{0.0, 0.0};
-                if constexpr (PFSITE(4)) rt_hl = IHL(0, rlane);
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
                     const int j = RW * s + rlane;
                     if constexpr (!PFSITE(3)) dpv[s] = 0;
-                    const d2 hl_pf = rt_hl;
-                    if constexpr (PFSITE(4)) if (s + 1 < IS) rt_hl = IHL(s + 1, RW * (s + 1) + rlane);
                     {
                         if (I_BOX(s)) {
                             if constexpr (!PFSITE(3)) {
@@ -1327,7 +1320,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             const d2 sh = ld2(Stash + 2 * RW * s);
                             dpv[s] = __builtin_fma(dlb, sh.x, -sh.y);   // dp = (-Np + dlam)/D
                             }
-                            const d2 hl = PFSITE(4) ? hl_pf : IHL(s, j);
+                            const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             double rzp, rzm; frcp_pair<PAIRSITE(4)>(izp[s], izm[s], rzp, rzm);
@@ -1359,9 +1352,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     status = 2; iterating = false;
                 } else {
                     double o_xi = 0.0, o_sg = 0.0;
-                    d2 up_hl = d2{0.0, 0.0}; double up_co = 0.0;
                     if constexpr (PFSITE(6)) { o_xi = A_(4, xi); o_sg = A_(5, sigma); }
-                    if constexpr (PFSITE(5)) { up_hl = IHL(0, rlane); up_co = ICOST(0, rlane); }
                     tp = row_max<RW>(tp); td = row_max<RW>(td);
                     if constexpr (!PFSITE(6)) o_xi = A_(4, xi);
                     alphap = tp > 0.0 ? vmin(o_xi * frcp(tp), 1.0) : 1.0;   // min(xi * min(z./-dz), 1)
@@ -1385,11 +1376,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
-                        const d2 hl_pf = up_hl; const double co_pf = up_co;
-                        if constexpr (PFSITE(5)) if (s + 1 < IS) { up_hl = IHL(s + 1, RW * (s + 1) + rlane); up_co = ICOST(s + 1, RW * (s + 1) + rlane); }
                         if (I_BOX(s)) {
                             const int j = RW * s + rlane;
-                            const d2 hl = PFSITE(5) ? hl_pf : IHL(s, j);
+                            const d2 hl = IHL(s, j);
                             const double hp = ip[s] - hl.x, hm = ILOV(s, hl.y) - ip[s];
                             const double dzp = -hp - izp[s] - dpv[s], dzm = -hm - izm[s] + dpv[s];
                             double rzp, rzm; frcp_pair<PAIRSITE(7)>(izp[s], izm[s], rzp, rzm);
@@ -1400,7 +1389,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             imup[s] = __builtin_fma(alphad, dmup, imup[s]); imum[s] = __builtin_fma(alphad, dmum, imum[s]);
                             zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                         }
-                        fl = __builtin_fma(PFSITE(5) ? co_pf : ICOST(s, RW * s + rlane), ip[s], fl);      // p = 0 on an injection out of service
+                        fl = __builtin_fma(ICOST(s, RW * s + rlane), ip[s], fl);      // p = 0 on an injection out of service
                         SLOT_FENCE_AT(5);
                     }
 #pragma unroll
