@@ -184,13 +184,10 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define RELOAD_FENCE() __asm__ volatile("" ::: "memory")
 // keeps the unrolled per-slot bodies from being interleaved (each body has ~20 live temporaries)
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
-// A/B (RELMC_FENCE_MASK, default all six sites): bit k = 0 lets the scheduler interleave the slot bodies of site k
-// (0 / 1 evaluation lines / injections, 2 / 3 ratio tests, 4 / 5 update)
-#ifndef RELMC_FENCE_MASK
-#define RELMC_FENCE_MASK 0x3f
-#endif
-// LDS round trips of the vector phases taken off the wavefront's critical path (RELMC_PF_MASK, bit k = site k): operands of the NEXT slot
-// are requested before the current slot is worked on, and loads that sat in separate branches are issued as one batch.  Same arithmetic.
+// (round 3 re-measured every one of the six fence sites: removing any of them is neutral on the 16-lane tile and 0.3-2.7 % slower on the
+// wide one, profiles/r3_pf/c11_*.log)
+// LDS round trips of the vector phases taken off the wavefront's critical path (RELMC_PF_MASK, bit k = site k): table words are requested
+// before the work that hides their latency instead of right where they are used.  Same arithmetic.
 //   1 assembly: block offsets before the gathers                       2 gathers: incidence lists of both bus slots up front
 //   3 step: the lines' and injections' solution entries as one batch   6 / 7 step / convergence test: solver options requested before the row reductions
 // (sites 0, 4, 5 -- injection bounds / cost / lambda one slot ahead in the evaluation, the ratio tests, the update -- were measured neutral
@@ -202,7 +199,6 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define RELMC_PF_MASK_WIDE 0xc6     // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
 #endif
 #define PFSITE(k) (((PF_MASK >> (k)) & 1) != 0)
-#define SLOT_FENCE_AT(k) do { if constexpr (((RELMC_FENCE_MASK >> (k)) & 1) != 0) __builtin_amdgcn_sched_barrier(0); } while (0)
 // optional per-phase cycle accounting (profiling builds only: -DRELMC_PHASE_TIMING)
 #ifdef RELMC_PHASE_TIMING
 #define PT_DECL unsigned long long pt_[8] = {0, 0, 0, 0, 0, 0, 0, 0}; unsigned long long pt0_ = __builtin_readcyclecounter();
@@ -852,7 +848,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     gown[s] = g;
                     if (l < nlp) { st2(LR + 4 * l, g, lx); st2(LR + 4 * l + 2, lx + q, LFv[s]); }   // nl / ninj records (they alias W)
-                    SLOT_FENCE_AT(0);
+                    SLOT_FENCE();
                 }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
@@ -886,7 +882,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     }
                     if (j < nip) IR[j] = pv;
                     st2(Stash + 2 * RW * s, invD, npd);
-                    SLOT_FENCE_AT(1);
+                    SLOT_FENCE();
                 }
                 PT_MARK(1)
                 if (rlane == 0) { st2(LR + 4 * nlp, 0.0, 0.0); st2(LR + 4 * nlp + 2, 0.0, 0.0); IR[nip] = 0.0; }
@@ -1271,17 +1267,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     d2 xf[LS], xt[LS], sh[IS]; double dlb[IS];
 #pragma unroll
                     for (int s = 0; s < LS; ++s) { xf[s] = ld2(X + 2 * (linfo[s] & 0xff)); xt[s] = ld2(X + 2 * ((linfo[s] >> 8) & 0xff)); }
-#ifdef RELMC_PF3_SPLIT       // A/B: two batches (lines, then injections) instead of one: fewer values in flight
-#pragma unroll
-                    for (int s = 0; s < LS; ++s) { dF[s] = L_ON(s) ? lb(s) * (xf[s].x - xt[s].x) : 0.0; dG[s] = L_ON(s) ? lb(s) * (xf[s].y - xt[s].y) : 0.0; }
-                    SLOT_FENCE();
-#endif
 #pragma unroll
                     for (int s = 0; s < IS; ++s) { dlb[s] = X[2 * (iinfo[s] & 0xff) + 1]; sh[s] = ld2(Stash + 2 * RW * s); }
-#ifndef RELMC_PF3_SPLIT
 #pragma unroll
                     for (int s = 0; s < LS; ++s) { dF[s] = L_ON(s) ? lb(s) * (xf[s].x - xt[s].x) : 0.0; dG[s] = L_ON(s) ? lb(s) * (xf[s].y - xt[s].y) : 0.0; }
-#endif
 #pragma unroll
                     for (int s = 0; s < IS; ++s) dpv[s] = I_BOX(s) ? __builtin_fma(dlb[s], sh[s].x, -sh[s].y) : 0.0;
                 }
@@ -1307,7 +1296,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             td = vmax(td, vmax(-dmup * rmp, -dmum * rmm));
                         }
                     }
-                    SLOT_FENCE_AT(2);
+                    SLOT_FENCE();
                 }
 #pragma unroll
                 for (int s = 0; s < IS; ++s) {
@@ -1332,7 +1321,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             step2 = __builtin_fma(dpv[s], dpv[s], step2);
                         }
                     }
-                    SLOT_FENCE_AT(3);
+                    SLOT_FENCE();
                 }
                 step2 = row_sum<RW>(step2);
 #ifdef RELMC_TRACE
@@ -1372,7 +1361,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         }
                         LFv[s] = __builtin_fma(alphap, dF[s], LFv[s]);      // dF = dG = 0 on a line out of service
                         LGv[s] = __builtin_fma(alphad, dG[s], LGv[s]);
-                        SLOT_FENCE_AT(4);
+                        SLOT_FENCE();
                     }
 #pragma unroll
                     for (int s = 0; s < IS; ++s) {
@@ -1390,7 +1379,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             zl = __builtin_fma(izp[s], imup[s], zl); zl = __builtin_fma(izm[s], imum[s], zl);
                         }
                         fl = __builtin_fma(ICOST(s, RW * s + rlane), ip[s], fl);      // p = 0 on an injection out of service
-                        SLOT_FENCE_AT(5);
+                        SLOT_FENCE();
                     }
 #pragma unroll
                     for (int t = 0; t < BS; ++t) {
