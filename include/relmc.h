@@ -339,6 +339,20 @@ int32_t relmc_retry_dense_stats(const relmc_ctx* ctx, int64_t* units_out, int64_
  * default (level-then-fill), 1 = the same with the ties broken the other way, 2 = fill first; probe_failures_out: failures of each
  * probed order among the 8192 (-1 = not probed).  RTS-24 and RTS-96: {0, -1, -1}, nothing changes. */
 int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t probe_failures_out[3]);
+/* The primary order as a tunable of the schedule.  The Newton step of every scenario runs a static pass program that relmc_case_load
+ * derives from the elimination order of the buses (MATLAB's `\` under mips picks its own pivot order per call, mc_simulation.m:41); the
+ * built-in rule (shallow elimination tree first, then little fill) is good, an order searched against the scheduler itself is better:
+ * RTS-24 174 -> 168 LDS instructions per Newton step (-1.5 % kernel time), RTS-96 215 -> 201 and 32 -> 29 dependent passes (-3.1 %).
+ *   relmc_tune_order       host only (no device, no context): simulated annealing over bus permutations, `evaluations` runs of the scheduler
+ *                          (3 ms each on RTS-96), deterministic in `seed`; start = NULL begins at the rule's order.  order_out[nb] = external
+ *                          bus numbers in elimination order, the reference bus last; stats_out (optional) = {LDS instructions per Newton step,
+ *                          dependent passes} of the start order and of the result.  An order never changes WHAT is computed, only the
+ *                          rounding of the factorisation (iteration counts of single states may move by one).
+ *   relmc_case_order_hint  the order for the NEXT relmc_case_load of this context (copied; NULL / 0 = the rule); the load fails with
+ *                          RELMC_ERR_INVALID if it is not a permutation of 0..nb-1 with the reference bus last.  The further orders of
+ *                          the retry path (relmc_retry_stats) stay rule-made. */
+int32_t relmc_tune_order(const relmc_case_desc* desc, int32_t evaluations, uint64_t seed, const int32_t* start, int32_t* order_out, int32_t stats_out[4]);
+int32_t relmc_case_order_hint(relmc_ctx* ctx, const int32_t* order, int32_t n);
 
 /* ---- nsqMain (nsqMain.m:208-318 + 345-376) ------------------------------------------- */
 /* Batches of up to 8192 samples (the reference's is 100, nsqMain.m:60) are evaluated many at a time in the modes

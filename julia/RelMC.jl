@@ -87,7 +87,9 @@ end
 
 check(rc, h, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:relmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
 
-function Engine(sys::TestSystem; device::Integer=0)
+# `elim_order`: optional primary elimination order of the device solver's static schedule (0-based bus numbers, the reference bus last),
+# e.g. one found by `tune_order` below; `nothing` = the library's rule (relmc_case_order_hint).
+function Engine(sys::TestSystem; device::Integer=0, elim_order::Union{Nothing,Vector{Int32}}=nothing)
     h = Ref{Ptr{Cvoid}}(C_NULL)
     rc = ccall((:relmc_ctx_create, LIB), Int32, (Int32, Ref{Ptr{Cvoid}}), device, h)
     rc == 0 || error("relmc_ctx_create failed ($rc): no usable HIP device (there is no CPU fallback)")
@@ -97,6 +99,9 @@ function Engine(sys::TestSystem; device::Integer=0)
                      pointer(sys.inj_bus), pointer(sys.inj_pmin), pointer(sys.inj_pmax), pointer(sys.inj_cost),
                      pointer(sys.br_from), pointer(sys.br_to), pointer(sys.br_b), pointer(sys.br_rate),
                      pointer(sys.unavail), pointer(sys.always_up), sys.load)
+        if elim_order !== nothing
+            check(ccall((:relmc_case_order_hint, LIB), Int32, (Ptr{Cvoid}, Ptr{Int32}, Int32), eng.h, elim_order, length(elim_order)), eng.h, "relmc_case_order_hint")
+        end
         check(ccall((:relmc_case_load, LIB), Int32, (Ptr{Cvoid}, Ref{CaseDesc}), eng.h, Ref(d)), eng.h, "relmc_case_load")
     end
     finalizer(e -> ccall((:relmc_ctx_destroy, LIB), Cvoid, (Ptr{Cvoid},), e.h), eng)
@@ -183,6 +188,25 @@ function case_order(eng::Engine)
     p = Ref{Int32}(0); f = zeros(Int32, 3)
     check(ccall((:relmc_case_order, LIB), Int32, (Ptr{Cvoid}, Ref{Int32}, Ptr{Int32}), eng.h, p, f), eng.h, "relmc_case_order")
     return (Int(p[]), f)
+end
+"""
+    tune_order(sys; evaluations=20000, seed=1, start=nothing) -> (order, (lds_before, passes_before, lds_after, passes_after))
+
+relmc_tune_order: host-only search of the primary elimination order against the library's own scheduler (no GPU needed); pass the result to
+`Engine(sys; elim_order=order)`.
+"""
+function tune_order(sys::TestSystem; evaluations::Integer=20000, seed::Integer=1, start::Union{Nothing,Vector{Int32}}=nothing)
+    order = zeros(Int32, sys.nb); st = zeros(Int32, 4)
+    GC.@preserve sys begin
+        d = CaseDesc(sys.base_mva, sys.nb, sys.ng, sys.nl, sys.nd, sys.ref_bus, pointer(sys.bus_pd),
+                     pointer(sys.inj_bus), pointer(sys.inj_pmin), pointer(sys.inj_pmax), pointer(sys.inj_cost),
+                     pointer(sys.br_from), pointer(sys.br_to), pointer(sys.br_b), pointer(sys.br_rate),
+                     pointer(sys.unavail), pointer(sys.always_up), sys.load)
+        rc = ccall((:relmc_tune_order, LIB), Int32, (Ref{CaseDesc}, Int32, UInt64, Ptr{Int32}, Ptr{Int32}, Ptr{Int32}),
+                   Ref(d), evaluations, seed, start === nothing ? C_NULL : start, order, st)
+        rc == 0 || error("relmc_tune_order failed ($rc)")
+    end
+    return order, Tuple(Int.(st))
 end
 "(rows, samples) of the state database"
 function db_size(eng::Engine)

@@ -26,6 +26,7 @@ EXPORTS = [
     "relmc_comm_unique_id", "relmc_comm_init", "relmc_comm_allreduce_acc", "relmc_comm_destroy", "relmc_comm_set_host_allreduce", "relmc_comm_info",
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_retry_dense_stats", "relmc_case_order",
+    "relmc_case_order_hint", "relmc_tune_order",
 ]
 
 
@@ -134,6 +135,10 @@ def load():
         L.relmc_debug_mc_simulation_dense.restype = C.c_int32
     L.relmc_case_order.argtypes = [vp, i32p, i32p]
     L.relmc_case_order.restype = C.c_int32
+    L.relmc_case_order_hint.argtypes = [vp, i32p, C.c_int32]
+    L.relmc_case_order_hint.restype = C.c_int32
+    L.relmc_tune_order.argtypes = [C.c_void_p, C.c_int32, C.c_uint64, i32p, i32p, i32p]
+    L.relmc_tune_order.restype = C.c_int32
     L.relmc_db_export.argtypes = [vp, C.c_int64, C.c_int64, u8p, _abi.c_int64_p, dp, i32p, dp, i32p, i32p, u8p]
     L.relmc_db_export.restype = C.c_int32
     L.relmc_db_import.argtypes = [vp, C.c_void_p, C.c_int64, u8p, _abi.c_int64_p, dp, dp, i32p, i32p, u8p]

@@ -133,10 +133,27 @@ class NsqResult:
                            beta_history=self.beta_history[None, :], edns_history=self.edns_history[None, :]))
 
 
+def tune_order(case: case24.Case, evaluations: int = 20000, seed: int = 1, start=None):
+    """relmc_tune_order (host only, no GPU): searches the primary elimination order of `case` against the library's own scheduler.
+    Returns (order [nb] int32, dict(lds_before, passes_before, lds_after, passes_after)): LDS instructions per Newton step and
+    dependent passes of the start order (the rule's when start is None) and of the result."""
+    L = _lib.load()
+    holder = _abi.CaseHolder(case)
+    out = np.zeros(case.nb, dtype=np.int32); st = np.zeros(4, dtype=np.int32)
+    s0 = None if start is None else np.ascontiguousarray(start, dtype=np.int32)
+    if s0 is not None and s0.size != case.nb:
+        raise ValueError("start must list every bus once")
+    rc = L.relmc_tune_order(C.addressof(holder.desc), int(evaluations), int(seed), None if s0 is None else s0.ctypes.data_as(_abi.c_int32_p),
+                            out.ctypes.data_as(_abi.c_int32_p), st.ctypes.data_as(_abi.c_int32_p))
+    if rc != 0:
+        raise RelmcError(f"relmc_tune_order failed ({rc})")
+    return out, dict(lds_before=int(st[0]), passes_before=int(st[1]), lds_after=int(st[2]), passes_after=int(st[3]))
+
+
 class Engine:
     """One context = one GPU (one process per GPU).  Owns the device-resident case tables."""
 
-    def __init__(self, case: case24.Case | None = None, device: int = 0):
+    def __init__(self, case: case24.Case | None = None, device: int = 0, elim_order="case"):
         self.L = _lib.load()
         h = C.c_void_p()
         rc = self.L.relmc_ctx_create(int(device), C.byref(h))
@@ -147,7 +164,7 @@ class Engine:
         self.device = device
         self.case = None
         self._holder = None
-        self.load_case(case or case24.rts24())
+        self.load_case(case or case24.rts24(), elim_order)
 
     # -- lifetime ---------------------------------------------------------------------------
     def close(self):
@@ -167,8 +184,17 @@ class Engine:
             raise RelmcError(f"{what} failed ({rc}): {msg.decode() if msg else ''}")
 
     # -- setup ------------------------------------------------------------------------------
-    def load_case(self, case: case24.Case):
+    def load_case(self, case: case24.Case, elim_order="case"):
+        """relmc_case_load.  elim_order: the primary elimination order of the solver schedule (external bus numbers, reference bus last:
+        relmc_case_order_hint) -- "case" takes `case.elim_order` when the case carries one (the RTS-24 / RTS-96 orders of this package were
+        tuned offline with `tune_order`), None the library's rule."""
         holder = _abi.CaseHolder(case)
+        order = getattr(case, "elim_order", None) if isinstance(elim_order, str) and elim_order == "case" else elim_order
+        if order is not None:
+            o = np.ascontiguousarray(order, dtype=np.int32)
+            self._check(self.L.relmc_case_order_hint(self._h, o.ctypes.data_as(_abi.c_int32_p), int(o.size)), "relmc_case_order_hint")
+        else:
+            self._check(self.L.relmc_case_order_hint(self._h, None, 0), "relmc_case_order_hint")
         self._check(self.L.relmc_case_load(self._h, C.byref(holder.desc)), "relmc_case_load")
         self.case, self._holder = case, holder
 

@@ -150,6 +150,7 @@ class Case:
     unavail: np.ndarray       # [ng+nl] failure probabilities (failprob.m)
     always_up: np.ndarray     # [ng+nl] uint8, 1 = never sampled as failed (mc_sampling.m:40-41)
     total_load: float = field(default=0.0)  # TestSystem.load, nsqMain.m:125
+    elim_order: np.ndarray | None = None    # optional schedule tunable: primary elimination order of the solver (0-based buses, reference bus last; relmc_case_order_hint)
 
     @property
     def ncomp(self) -> int:
@@ -166,6 +167,16 @@ def dispatchable_load_model(bus_pd: np.ndarray):
     pmin = -bus_pd[load_buses]
     pmax = np.zeros(load_buses.size)
     return load_buses.astype(np.int32), pmin, pmax
+
+
+# Primary elimination order of the device solver's static schedule for this network (0-based bus numbers, reference bus last), tuned offline
+# against the library's own scheduler: `python scripts/order_tune.py rts24 11 60000` = relmc_tune_order(evaluations=60000, seed=11) from the
+# built-in rule's order: 174 -> 168 LDS instructions per Newton step, 21 dependent passes as before, kernel 17.75 -> 17.50 ms per 1e6 scenarios.
+# An order changes only the rounding of the factorisation, but this LP's optimal face is degenerate, so it can move a state's nodal split:
+# of 18 orders tuned this way (seeds 1-20; profiles/r3_order/select24.log) 4 move the 0.3 percent-mass fixture state "G24 + G33 out" by one
+# iteration and 8 move bus 8's nodal sum of 3e5 sampled states by 0.2-0.4 percent against the C oracle; 6 keep both pins (every fixture
+# state's iteration count, every bus' nodal sum within 6e-4 -- the rule's order: 3.3e-4), and the fastest of those is this one (3.8e-4).
+RTS24_ELIM_ORDER = np.array([4, 21, 18, 5, 19, 17, 3, 6, 22, 23, 1, 20, 2, 11, 13, 16, 10, 0, 14, 15, 7, 8, 9, 12], dtype=np.int32)
 
 
 def rts24() -> Case:
@@ -186,6 +197,7 @@ def rts24() -> Case:
         br_b=1.0 / (BR_X * tap), br_rate=BR_RATE.copy(),
         unavail=failprob(), always_up=always_up,
         total_load=float(BUS_PD.sum()),
+        elim_order=RTS24_ELIM_ORDER.copy(),
     )
 
 

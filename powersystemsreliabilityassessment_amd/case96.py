@@ -65,6 +65,14 @@ def seqmeantime96() -> np.ndarray:
     return np.column_stack([np.concatenate([d["genmttf"], 8760.0 / d["brlambda"]]), np.concatenate([d["genmttr"], d["brdur"]])])
 
 
+# Primary elimination order of the device solver's static schedule (0-based bus numbers, reference bus last), tuned offline against the
+# library's own scheduler: scripts/order_search.py (critical-path model, seed 1: 19 -> 17 update passes) refined by
+# `python scripts/order_tune.py rts96 1 60000 <that order>` = relmc_tune_order(evaluations=60000, seed=1, start=...).
+# 215 -> 200 LDS instructions per Newton step, 32 -> 28 dependent passes (update 19 -> 16, back substitution 11 -> 10); kernel 73.7 -> 71.6 ms
+# per 1e6 scenarios; the primary order fails about as often as the rule's (107-118 against 110 units per 2e8 samples, all converge further on).
+RTS96_ELIM_ORDER = np.array([69, 41, 27, 3, 61, 2, 67, 42, 4, 17, 47, 60, 11, 53, 66, 18, 36, 54, 43, 5, 52, 71, 24, 51, 59, 64, 30, 44, 21, 6, 62, 29, 37, 14, 58, 48, 35, 55, 7, 49, 28, 68, 1, 34, 13, 25, 19, 31, 45, 40, 23, 56, 16, 38, 72, 65, 0, 57, 10, 33, 32, 39, 63, 15, 50, 9, 8, 70, 26, 22, 20, 46, 12], dtype=np.int32)
+
+
 def rts96() -> Case:
     nb = 24 * N_AREAS + 1
     bus_pd = np.concatenate([np.tile(case24.BUS_PD, N_AREAS), [0.0]])
@@ -85,4 +93,4 @@ def rts96() -> Case:
         inj_pmin=np.concatenate([gen_pmin, vpmin]), inj_pmax=np.concatenate([gen_pmax, vpmax]),
         inj_cost=np.concatenate([np.zeros(ng), np.ones(load_buses.size)]),
         br_from=br_from, br_to=br_to, br_b=br_b, br_rate=br_rate,
-        unavail=failprob96(), always_up=always_up, total_load=float(bus_pd.sum()))
+        unavail=failprob96(), always_up=always_up, total_load=float(bus_pd.sum()), elim_order=RTS96_ELIM_ORDER.copy())

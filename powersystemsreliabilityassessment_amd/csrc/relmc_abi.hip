@@ -29,6 +29,8 @@ static_assert(sizeof(DevAcc) == sizeof(relmc_acc), "device accumulator image mus
 
 struct relmc_ctx {
     int device = -1;
+    std::vector<int32_t> order_hint;     // relmc_case_order_hint: primary elimination order of the next relmc_case_load (external bus numbers), empty = the rule
+    int place_moves = -1;                // >= 0: overrides the placement-search length (the order tuner runs the scheduler without it)
     hipStream_t stream = nullptr;
     hipEvent_t ev0 = nullptr, ev1 = nullptr;
     bool has_case = false;
@@ -253,8 +255,25 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
     std::vector<int> ext2int(nb, -1), level(nb, -1);
     std::vector<char> gone(nb, 0);
     std::vector<std::vector<int>> hi_ext(nb);          // higher neighbours (external ids) at elimination time
+    // experiments (scripts/order_search.py): RELMC_ORDER = the primary order as a comma-separated list of external bus numbers, reference bus last
+    // The primary order may come from the host (relmc_case_order_hint: an order tuned offline by relmc_tune_order against this very
+    // scheduler; RELMC_ORDER = the same as a comma-separated list, for experiments); the further orders of the retry path stay rule-made.
+    std::vector<int> forced;
+    if (order_variant == 0 && !ctx->order_hint.empty()) forced.assign(ctx->order_hint.begin(), ctx->order_hint.end());
+    else if (order_variant == 0 && getenv("RELMC_ORDER")) {
+        const char* q = getenv("RELMC_ORDER");
+        while (*q) { char* e = nullptr; const long v = strtol(q, &e, 10); if (e == q) break; forced.push_back((int)v); q = *e ? e + 1 : e; }
+    }
+    if (!forced.empty()) {
+        std::vector<char> seen(nb, 0);
+        bool ok = (int)forced.size() == nb && forced.back() == d->ref_bus;
+        for (int v : forced) { if (v < 0 || v >= nb || seen[v]) ok = false; else seen[v] = 1; }
+        if (!ok) return fail(ctx, RELMC_ERR_INVALID, "relmc_case_load: the elimination-order hint is not a permutation of the buses with the reference bus last");
+    }
     for (int step = 0; step < nb; ++step) {
         int best = -1; long bestkey = 0;
+        if (!forced.empty()) best = forced[step];
+        else
         for (int b = 0; b < nb; ++b) {
             if (gone[b] || (b == d->ref_bus && step < nb - 1)) continue;
             int deg = 0, fillc = 0, lev = 0;
@@ -570,7 +589,7 @@ int case_symbolic(relmc_ctx* ctx, const relmc_case_desc* d, DevCaseT<TL>& C, int
             std::vector<int> touched; std::vector<long> newc;
             // 100 moves per block: 36 / 114 ms of relmc_case_load on RTS-24 / RTS-96; 400 (round 1) took 144 / 440 ms for kernel times within
             // run-to-run noise of these (19.0 vs 19.2 ms, 78.4 vs 78.2 ms per 1e6); no search at all: 19.2 / 79.3 ms
-            const int moves = noff > 0 ? (getenv("RELMC_PLACE_MOVES") ? atoi(getenv("RELMC_PLACE_MOVES")) : 100) * (nb + noff) : 0;
+            const int moves = noff > 0 ? (ctx->place_moves >= 0 ? ctx->place_moves : (getenv("RELMC_PLACE_MOVES") ? atoi(getenv("RELMC_PLACE_MOVES")) : 100)) * (nb + noff) : 0;
             for (int it = 0; it < moves && total > 0; ++it) {
                 if (rnd(10) < 6) {                                  // swap the positions of two off-diagonal blocks
                     const int i = nb + rnd(noff), j = nb + rnd(noff);
@@ -1255,6 +1274,71 @@ int pipe_run(relmc_ctx* ctx, const uint8_t* states, const double* load_scale, in
 
 }  // namespace
 
+namespace {
+// what the solver phase of one Newton step costs under a schedule: its LDS instructions (a pass costs them whatever its fill) + kPassWeight
+// per dependent pass (the update passes are LDS-pipe-bound, and every pass is one more wait on the wavefront's chain)
+constexpr long kPassWeight = 4;
+template <class TL>
+long schedule_cost(const DevCaseT<TL>& C, int32_t* lds_out, int32_t* passes_out)
+{
+    const int nbwd = (int)C.npass - (int)C.npass_upd - (int)C.npass_inv;
+    const int nfull = (int)C.npass_upd - (int)C.npass_updh - (int)C.npass_updq;
+    long lds = 10L * nfull + 7L * C.npass_updh + 6L * C.npass_updq + 6L * C.npass_inv;
+    for (int k = 0; k < nbwd; ++k) lds += (k < 64 && ((C.bwd_half >> k) & 1ull)) ? 6 : 7;
+    if (lds_out) *lds_out = (int32_t)lds;
+    if (passes_out) *passes_out = (int32_t)C.npass;
+    return lds + kPassWeight * (long)C.npass;
+}
+template <class TL>
+int tune_order_impl(const relmc_case_desc* d, int32_t evaluations, uint64_t seed, const int32_t* start, int32_t* order_out, int32_t* stats)
+{
+    const int nb = d->nb;
+    auto ctx = std::make_unique<relmc_ctx>();
+    ctx->place_moves = 0;                               // the cost does not depend on the operand placement
+    auto C = std::make_unique<DevCaseT<TL>>();
+    SymGeom g;
+    std::vector<int32_t> cur(nb), best(nb), cand(nb);
+    int32_t lds = 0, np = 0;
+    if (start) cur.assign(start, start + nb);
+    else {                                              // the rule's order: external buses by internal number
+        const int rc = case_symbolic<TL>(ctx.get(), d, *C, 0, g);
+        if (rc) return rc;
+        for (int e = 0; e < nb; ++e) cur[C->b_int[e]] = e;
+    }
+    auto eval = [&](const std::vector<int32_t>& o, int32_t* l, int32_t* p) -> long {
+        ctx->order_hint = o;
+        if (case_symbolic<TL>(ctx.get(), d, *C, 0, g) != RELMC_OK) return 1L << 40;      // too much fill / too many passes for the tile: never accepted
+        return schedule_cost(*C, l, p);
+    };
+    long cc = eval(cur, &lds, &np);
+    if (cc >= (1L << 40)) return RELMC_ERR_INVALID;     // a start order that is not a permutation with the reference bus last, or does not fit
+    if (stats) { stats[0] = lds; stats[1] = np; }
+    long bc = cc; best = cur; int32_t blds = lds, bnp = np;
+    uint64_t rng = seed * 0x9E3779B97F4A7C15ull + 0xD1B54A32D192ED03ull;
+    auto rnd = [&]() { rng ^= rng << 13; rng ^= rng >> 7; rng ^= rng << 17; return rng; };
+    auto unif = [&]() { return (double)(rnd() >> 11) * (1.0 / 9007199254740992.0); };
+    double T = 1.2; int since = 0;
+    for (int it = 0; it < evaluations && nb > 2; ++it) {
+        const int i = (int)(rnd() % (uint64_t)(nb - 1)), j = (int)(rnd() % (uint64_t)(nb - 1));       // the reference bus stays last
+        if (i == j) continue;
+        cand = cur;
+        if (unif() < 0.5) std::swap(cand[i], cand[j]);
+        else { const int32_t v = cand[i]; cand.erase(cand.begin() + i); cand.insert(cand.begin() + j, v); }
+        int32_t l2 = 0, p2 = 0;
+        const long nc = eval(cand, &l2, &p2);
+        if (nc <= cc || unif() < std::exp((double)(cc - nc) / T)) {
+            cur = cand; cc = nc;
+            if (nc < bc) { bc = nc; best = cand; blds = l2; bnp = p2; since = 0; }
+        }
+        T = T * 0.9995 > 0.12 ? T * 0.9995 : 0.12;
+        if (++since > 1500) { cur = best; cc = bc; since = 0; }                                         // back to the best order found so far
+    }
+    for (int k = 0; k < nb; ++k) order_out[k] = best[k];
+    if (stats) { stats[2] = blds; stats[3] = bnp; }
+    return RELMC_OK;
+}
+}  // namespace
+
 extern "C" {
 
 const char* relmc_version(void) { return "relmc 0.6 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules + dense pivoted last resort, device state database, multi-rank loop)"; }
@@ -1369,11 +1453,29 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     if (nb <= Tile24::NBT && nl <= Tile24::NLT && ng + nd <= Tile24::NIT && ng + nl <= Tile24::NCOMPMAX) {
         ctx->tile = 0;
         const int rc = case_load_impl<Tile24>(ctx, d, ctx->hcase24);
+        ctx->order_hint.clear();                         // a hint is for one relmc_case_load
         return rc ? rc : order_calibrate(ctx);
     }
     ctx->tile = 1;
     const int rc = case_load_impl<Tile96>(ctx, d, ctx->hcase96);
+    ctx->order_hint.clear();
     return rc ? rc : order_calibrate(ctx);
+}
+
+int32_t relmc_case_order_hint(relmc_ctx* ctx, const int32_t* order, int32_t n)
+{
+    if (!ctx || n < 0 || (n > 0 && !order)) return RELMC_ERR_INVALID;
+    ctx->order_hint.assign(order, order + n);          // validated against the case by relmc_case_load
+    return RELMC_OK;
+}
+
+
+int32_t relmc_tune_order(const relmc_case_desc* d, int32_t evaluations, uint64_t seed, const int32_t* start, int32_t* order_out, int32_t stats_out[4])
+{
+    if (!d || !order_out || evaluations < 0 || d->nb < 1) return RELMC_ERR_INVALID;
+    if (d->nb <= Tile24::NBT && d->nl <= Tile24::NLT && d->ng + d->nd <= Tile24::NIT && d->ng + d->nl <= Tile24::NCOMPMAX)
+        return tune_order_impl<Tile24>(d, evaluations, seed, start, order_out, stats_out);
+    return tune_order_impl<Tile96>(d, evaluations, seed, start, order_out, stats_out);
 }
 
 int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t probe_failures_out[3])
@@ -2613,11 +2715,12 @@ int32_t relmc_debug_schedule(const relmc_ctx* ctx, int32_t* out9)
 //            nzero, scen_doubles, lds_bytes, modelled LDS conflict cycles before / after the placement search, MAXPASS, nl, 6 spare
 //   tasks[npass][RW][4] (0xffff = no task), pass_ntask[npass], b_int[nb] (external -> internal bus), l_blk[nl] (W offset of the owner
 //   line's block, 0xffff otherwise), l_info[nl] (from | to << 8 | flags << 24, internal bus numbers), zero_off[nzero]
-int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, int32_t* hdr, uint16_t* tasks, int64_t tasks_cap, uint8_t* pass_ntask,
+int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, const int32_t* order_hint, int32_t n_hint, int32_t* hdr, uint16_t* tasks, int64_t tasks_cap, uint8_t* pass_ntask,
                              uint8_t* b_int, uint16_t* l_blk, uint32_t* l_info, uint16_t* zero_off, char* err, int32_t err_cap)
 {
     if (!d || !hdr || !tasks || !pass_ntask || !b_int || !l_blk || !l_info || !zero_off) return RELMC_ERR_INVALID;
     auto ctx = std::make_unique<relmc_ctx>();              // host-side use only: collects the error text
+    if (order_hint && n_hint > 0) ctx->order_hint.assign(order_hint, order_hint + n_hint);
     SymGeom g;
     int rc;
     auto dump = [&](const auto& C, int tile, int rw, int maxpass) {

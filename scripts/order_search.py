@@ -79,7 +79,7 @@ def anneal(adj, order0, lanes, iters, seed):
     def cost(o):
         cp, tasks, h, cap = model(adj, o, lanes)
         return max(cp, cap) + 0.6 * (h - 1) + 0.002 * tasks, (cp, tasks, h, cap)
-    cur = list(order0); cc, ci = cost(cur); bc, bi = cc, ci
+    cur = list(order0); cc, ci = cost(cur); bc, bi, bo = cc, ci, list(cur)
     T = 0.5
     for _ in range(iters):
         i, j = rnd.randrange(n - 1), rnd.randrange(n - 1)          # the reference bus stays last
@@ -90,9 +90,9 @@ def anneal(adj, order0, lanes, iters, seed):
         nc, ni = cost(new)
         if nc <= cc or rnd.random() < np.exp((cc - nc) / T):
             cur, cc, ci = new, nc, ni
-            if nc < bc: bc, bi = nc, ni
+            if nc < bc: bc, bi, bo = nc, ni, list(new)
         T = max(0.02, T * 0.9997)
-    return bi
+    return bi, bo
 
 
 if __name__ == "__main__":
@@ -100,4 +100,5 @@ if __name__ == "__main__":
         adj = graph(c); o = shipped_rule(adj, int(c.ref_bus))
         print(name, "shipped rule: (critical path, update tasks, tree height, tasks / lanes) =", model(adj, o, lanes))
         for seed in (1, 2, 3):
-            print(name, "annealed, seed", seed, "->", anneal(adj, o, lanes, 20000 if c.nb < 40 else 40000, seed), flush=True)
+            bi, bo = anneal(adj, o, lanes, 20000 if c.nb < 40 else 40000, seed)
+            print(name, "annealed, seed", seed, "->", bi, "RELMC_ORDER=" + ",".join(str(v) for v in bo), flush=True)

@@ -21,10 +21,11 @@ static int32_t two_rank_allreduce(void* user, relmc_acc* acc)
     t->done += m; t->calls++;
     return 0;
 }
-static int run_two_ranks(const relmc_case_desc* d, const relmc_nsq_opts* o, const relmc_nsq_result* plain)
+static int run_two_ranks(const relmc_case_desc* d, const int32_t* order, const relmc_nsq_opts* o, const relmc_nsq_result* plain)
 {
     relmc_ctx *c0 = NULL, *c1 = NULL;
     if (relmc_ctx_create(0, &c0) != RELMC_OK || relmc_ctx_create(0, &c1) != RELMC_OK) return 1;
+    if (relmc_case_order_hint(c0, order, d->nb) != RELMC_OK || relmc_case_order_hint(c1, order, d->nb) != RELMC_OK) return 2;
     if (relmc_case_load(c0, d) != RELMC_OK || relmc_case_load(c1, d) != RELMC_OK) return 2;
     two_rank_t t = {c1, o, 0, 0};
     if (relmc_comm_set_host_allreduce(c0, 2, 0, two_rank_allreduce, &t) != RELMC_OK) return 3;
@@ -56,9 +57,15 @@ int main(int argc, char** argv)
     d.bus_pd = rd(f, 8 * d.nb); d.inj_bus = rd(f, 4 * ninj); d.inj_pmin = rd(f, 8 * ninj); d.inj_pmax = rd(f, 8 * ninj); d.inj_cost = rd(f, 8 * ninj);
     d.br_from = rd(f, 4 * d.nl); d.br_to = rd(f, 4 * d.nl); d.br_b = rd(f, 8 * d.nl); d.br_rate = rd(f, 8 * d.nl);
     d.unavail = rd(f, 8 * ncomp); d.always_up = rd(f, ncomp);
+    int32_t* order = rd(f, 4 * d.nb);                 /* primary elimination order of the solver schedule (the package's tuned order) */
     fclose(f);
     relmc_ctx* ctx = NULL;
     if (relmc_ctx_create(0, &ctx) != RELMC_OK) { fprintf(stderr, "no device\n"); return 3; }
+    /* the order hint: a non-permutation is refused by the load (and consumed: the next load is rule-made again), the real one accepted */
+    int32_t first = order[0]; order[0] = order[1];
+    if (relmc_case_order_hint(ctx, order, d.nb) != RELMC_OK || relmc_case_load(ctx, &d) != RELMC_ERR_INVALID) return 22;
+    order[0] = first;
+    if (relmc_case_order_hint(ctx, order, d.nb) != RELMC_OK) return 23;
     if (relmc_case_load(ctx, &d) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 4; }
     relmc_solver_opts o; relmc_solver_opts_default(&o);
     relmc_acc acc, acc2; int64_t nd = 0;
@@ -95,7 +102,7 @@ int main(int argc, char** argv)
     if (memcmp(&r_comm.acc, &r_plain.acc, sizeof(relmc_acc)) != 0 || r_comm.idx.beta != r_plain.idx.beta || r_comm.checkpoints != r_plain.checkpoints) return 20;
     /* the multi-rank loop itself (relmc_nsq_run with R > 1: contiguous split of every batch, one all-reduce per batch) on this one GPU:
      * a host collective for "2 ranks" whose transport is this process evaluating the OTHER rank's slice on a second context */
-    if (run_two_ranks(&d, &no, &r_plain) != 0) return 21;
+    if (run_two_ranks(&d, order, &no, &r_plain) != 0) return 21;
     printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
     relmc_ctx_destroy(ctx);
     return 0;

@@ -51,12 +51,13 @@ class Schedule:
         return self.npass - self.npass_upd - self.npass_inv
 
 
-def symbolic(case, order_variant: int = 0) -> Schedule:
+def symbolic(case, order_variant: int = 0, order=None) -> Schedule:
     L = _lib.load()
     f = L.relmc_debug_symbolic
     f.restype = C.c_int32
-    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                  C.c_char_p, C.c_int32]
+    f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
+                  C.c_void_p, C.c_char_p, C.c_int32]
+    hint = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
     holder = _abi.CaseHolder(case)
     hdr = np.zeros(24, np.int32)
     tasks = np.zeros(96 * 64 * 4, np.uint16)
@@ -66,7 +67,7 @@ def symbolic(case, order_variant: int = 0) -> Schedule:
     l_info = np.zeros(256, np.uint32)
     zero_off = np.zeros(512, np.uint16)
     err = C.create_string_buffer(512)
-    rc = f(C.byref(holder.desc), order_variant, hdr.ctypes.data, tasks.ctypes.data, tasks.size, pnt.ctypes.data, b_int.ctypes.data,
+    rc = f(C.byref(holder.desc), order_variant, None if hint is None else hint.ctypes.data, 0 if hint is None else int(hint.size), hdr.ctypes.data, tasks.ctypes.data, tasks.size, pnt.ctypes.data, b_int.ctypes.data,
            l_blk.ctypes.data, l_info.ctypes.data, zero_off.ctypes.data, err, 512)
     if rc != 0:
         raise RuntimeError(f"relmc_debug_symbolic failed ({rc}): {err.value.decode()}")

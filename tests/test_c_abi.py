@@ -40,6 +40,7 @@ def test_plain_c_client(tmp_path, case):
                      (case.inj_cost, np.float64), (case.br_from, np.int32), (case.br_to, np.int32), (case.br_b, np.float64),
                      (case.br_rate, np.float64), (case.unavail, np.float64), (case.always_up, np.uint8)):
             fh.write(np.ascontiguousarray(a, dtype=t).tobytes())
+        fh.write(np.ascontiguousarray(case.elim_order, dtype=np.int32).tobytes())      # relmc_case_order_hint: the engine below loads it too
     out = None
     for attempt in range(2):                      # the client takes ~7 s; one run in ~15 on the GPU pool stalled inside RCCL's one-rank bootstrap
         try:

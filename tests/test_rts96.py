@@ -123,7 +123,7 @@ def test_gpu96_accumulate_matches_oracle(engine96, oracle96):
     np.testing.assert_array_equal(ai[6:], ri[6:])                 # component-down counts during loss
     np.testing.assert_allclose(ad[:2], rd[:2], rtol=1e-8)         # sum dns, sum dns^2
     # Per-bus sums of the sampled run: 2 % (measured round 3: 0.84 %, 23 MW on the worst bus).  The split of a state's curtailment over
-    # the buses is a point of a degenerate optimal face; on the heavy-outage states of the fixtures (317 + 67 states, 112 GW shed in
+    # the buses is a point of a degenerate optimal face; on the heavy-outage states of the fixtures (317 + 67 states when measured, 112 GW shed in
     # total) device and C oracle end tens of MW apart on single buses with totals equal to 5e-4 MW (tests/tools/nodal96_agg.py: per-bus
     # sums over those states differ by 4 % in the median, 23 % at worst; the C oracle and the numpy restatement do the same to each
     # other), which is why that set pins totals, not buses.
@@ -206,7 +206,7 @@ def numfail96(case96_):
 
 
 def test_oracle96_on_device_numfail_states(oracle96, numfail96):
-    """All 67 states of a 1e8-sample run (seed 1) on which the DEVICE ended NUMFAIL, through the C oracle: it reproduces what
+    """All 51 states of a 1e8-sample run (seed 1) on which the DEVICE's primary order ended NUMFAIL, through the C oracle: it reproduces what
     it returned on the GPU box, its curtailment equals numpy MIPS' and HiGHS' to 1e-6 MW on every state, and the two LU-based
     oracles themselves disagree about the termination status on some of them (heavy-outage states whose Newton systems span
     16 decades: whether the four MIPS tests hold in the same iteration is decided by rounding)."""
@@ -221,28 +221,30 @@ def test_oracle96_on_device_numfail_states(oracle96, numfail96):
                 assert r["dns"][i] == pytest.approx(e["highs_dns"], abs=5e-5), (name, i)
             assert e["c_oracle"]["status"] in (0, 2) and e["numpy_mips"]["status"] in (0, 2)
             differ += int(e["c_oracle"]["status"] != e["numpy_mips"]["status"])
-        assert 1 <= differ <= 12                      # recorded: 7 of 67
+        assert 1 <= differ <= 12                      # recorded: 7 of 51
 
 
 @pytest.mark.gpu
 def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
-    """The 67 states (of 1e8 samples) on which the device's PRIMARY elimination order ends "numerically failed" (scanned in
-    round 2, fixture).  The curtailment is the optimum on every one of them (<= 1e-5 MW from the oracle, numpy MIPS and
-    HiGHS).  Every entry point now evaluates such a unit again under a second and, if need be, a third static order
-    (DESIGN.md 6.3): 66 converge under the second, the last one under the third; the C oracle converges on 62 of the 67."""
+    """The 51 states (of 1e8 samples, seed 1) on which the device's PRIMARY elimination order -- the tuned order the package ships for
+    RTS-96, scanned in round 3 with the retries off -- ends "numerically failed".  The curtailment is the optimum on every one of
+    them (<= 1e-5 MW from the oracle, numpy MIPS and HiGHS).  Every entry point evaluates such a unit again under a second and, if
+    need be, a third static order, and then with the dense pivoted solve."""
     from powersystemsreliabilityassessment_amd import api
     for name, pol in (("emulate", _abi.RELMC_REFERENCE_EMULATE), ("physical", _abi.RELMC_PHYSICAL)):
         before = engine96.retry_stats()
         dns, nodal, info = engine96.mc_simulation(numfail96["matrix"], mpopt=api.mpoption(pol), return_info=True)
         after = engine96.retry_stats()
-        assert after[0] - before[0] == 67 and after[1] - before[1] >= 66          # all 67 went to the further orders
+        N = len(numfail96["states"])
+        assert after[0] - before[0] == N and after[1] - before[1] >= N - 1          # all of them went to the further orders
         r = oracle96.mc_simulation(numfail96["matrix"], pol, nthreads=16)
         np.testing.assert_allclose(dns, r["dns"], rtol=0, atol=1e-5)
         assert set(np.unique(info["status"])) <= {0, 2}
         dev_ok, orc_ok = info["status"] == 0, r["status"] == 0
-        assert dev_ok.sum() >= 66 and (dev_ok & orc_ok).sum() >= 61
+        assert dev_ok.sum() >= N - 1 and (dev_ok & orc_ok).sum() >= orc_ok.sum() - 1
         both = dev_ok & orc_ok
-        assert np.abs(info["iters"][both] - r["iters"][both]).max() <= 5 and (info["iters"][both] == r["iters"][both]).mean() > 0.75
+        # heavy-outage states solved under the further orders: the iteration counts agree on most and differ by a few on the rest (recorded: 6 at most)
+        assert np.abs(info["iters"][both] - r["iters"][both]).max() <= 8 and (info["iters"][both] == r["iters"][both]).mean() > 0.75
         for i, x in enumerate(numfail96["states"]):
             e = x[name]
             assert dns[i] == pytest.approx(e["numpy_mips"]["dns"], abs=1e-5)
@@ -253,9 +255,9 @@ def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
 
 @pytest.mark.gpu
 def test_gpu96_dense_last_resort_on_the_numfail_states(engine96, oracle96, numfail96):
-    """The 67 RTS-96 states the primary static order ends 'numerically failed' on, through the dense partially pivoted solve alone (the
+    """The 51 RTS-96 states the primary static order ends 'numerically failed' on, through the dense partially pivoted solve alone (the
     third retry level, reached by 2 units in 1e9 samples once the further static orders have had their turn): it converges on at least as
-    many as the C oracle's pivoted LU does on the same states (62 of 67), agrees with the oracle's status on nearly all, and the
+    many as the C oracle's pivoted LU does on the same states, agrees with the oracle's status on nearly all, and the
     curtailment equals the oracle's to 1e-5 MW on every state whatever the status."""
     from powersystemsreliabilityassessment_amd import api
     st = numfail96["matrix"]
@@ -302,14 +304,14 @@ def test_gpu96_retry_in_every_path(engine96, numfail96):
 @pytest.mark.gpu
 def test_gpu96_retry_through_the_scaled_load_entry_point(seqeng96, engine96, numfail96):
     """seq_mcsimulation (host buffers, per-state load scale) on the fixture's states: scale 1 must give mc_simulation's
-    results (all 67 go through the further orders with their scale), and a scale of 0.97 still converges everywhere."""
+    results (all of them go through the further orders with their scale), and a scale of 0.97 still converges everywhere."""
     from powersystemsreliabilityassessment_amd import api
     st = numfail96["matrix"]
     u0 = engine96.retry_stats()[0]
     d1, n1, i1 = seqeng96.seq_mcsimulation(st, 1.0, return_info=True)
     u1 = engine96.retry_stats()[0]
     d0, n0, i0 = engine96.mc_simulation(st, return_info=True)
-    assert u1 - u0 == 67
+    assert u1 - u0 == len(st)
     np.testing.assert_array_equal(d1, d0); np.testing.assert_array_equal(n1, n0)
     np.testing.assert_array_equal(i1["status"], i0["status"]); np.testing.assert_array_equal(i1["iters"], i0["iters"])
     d2, n2, i2 = seqeng96.seq_mcsimulation(st, np.full(len(st), 0.97), return_info=True)
@@ -318,8 +320,8 @@ def test_gpu96_retry_through_the_scaled_load_entry_point(seqeng96, engine96, num
 
 @pytest.mark.gpu
 def test_gpu96_nonconverged_rate(engine96):
-    """2e7 scenarios: the primary order ends 6.7e-7 of them non-converged (13 expected here), the further orders none
-    (0 of the 67 in the first 1e8 samples, scripts/retry_soak.py)."""
+    """2e7 scenarios: the primary order ends 5e-7 of them non-converged (10 expected here), the further orders none
+    (0 of the 51 in the first 1e8 samples, scripts/order_soak.py)."""
     u0 = engine96.retry_stats()[0]
     acc = engine96.nsq_accumulate(1, 0, 20_000_000)
     assert acc.n_nonconverged <= 1 and 3 <= engine96.retry_stats()[0] - u0 <= 40

@@ -8,7 +8,9 @@ from oracle import coracle
 N = int(float(sys.argv[1])) if len(sys.argv) > 1 else 1_000_000
 which = sys.argv[2] if len(sys.argv) > 2 else "rts24"
 c = case24.rts24() if which == "rts24" else case96.rts96()
-eng = api.Engine(c); orc = coracle.Oracle(c)
+order = "case"                      # argv[3]: "rule" = the library's rule, a file name = that order, default = the order the package ships
+if len(sys.argv) > 3: order = None if sys.argv[3] == "rule" else np.array([int(v) for v in open(sys.argv[3]).read().strip().split(",")], np.int32)
+eng = api.Engine(c, elim_order=order); orc = coracle.Oracle(c)
 CH = 250_000
 for name, pol in (("emulate", 0), ("physical", 1)):
     tot = dict(n=0, status=0, dns6=0, it1=0, it2=0, nc_dev=0, nc_orc=0); maxd = 0.0
@@ -26,6 +28,8 @@ for name, pol in (("emulate", 0), ("physical", 1)):
         tot["nc_dev"] += int(np.isin(info["status"], (1, 2)).sum()); tot["nc_orc"] += int(np.isin(r["status"], (1, 2)).sum())
         nod_d += nodal.sum(0); nod_o += r["nodal"].sum(0); sd += dns.sum(); so += r["dns"].sum()
     m = nod_o > 0
+    rel = np.zeros(c.nb); rel[m] = np.abs(nod_d[m] - nod_o[m]) / nod_o[m]
+    print("   per-bus rel diff of the nodal sums, worst three (bus, rel):", [(int(i) + 1, float("%.2e" % rel[i])) for i in np.argsort(-rel)[:3]])
     print("%s %s: %d sampled states in %.0f s: status differs %d, |ddns| > 1e-6 MW %d (max %.2e), iterations +-1 %d (%.4f %%), beyond %d; non-converged device %d / oracle %d; "
           "sum dns rel diff %.2e; per-bus nodal sums rel diff max %.2e" % (which, name, tot["n"], time.time() - t, tot["status"], tot["dns6"], maxd, tot["it1"], 100.0 * tot["it1"] / tot["n"],
           tot["it2"], tot["nc_dev"], tot["nc_orc"], abs(sd - so) / so, (np.abs(nod_d[m] - nod_o[m]) / nod_o[m]).max()), flush=True)
