@@ -225,6 +225,7 @@ def main():
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
             "vs_baseline": None, "dtype": "f64", "data": "synthetic",
             "config": {"workload": workload, "policy": args.policy, "seed": args.seed,
+                       "solver_schedule": schedule_summary(eng, case),
                        "parallelism": f"scenario-index{' / year' if args.workload == 'seq' else ''} sharding x{world}, 1 all-reduce of relmc_acc per step "
                                       f"({comm.kind + ' through the C ABI' if comm is not None else 'torch.distributed ' + (pg_backend if world > 1 else '(single rank: no collective)')})"},
             "roofline": roof,
@@ -273,6 +274,17 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def schedule_summary(eng, case):
+    """Which static pass program the kernel interprets: passes per Newton step and where its elimination order comes from."""
+    import ctypes as C
+    out = (C.c_int32 * 9)()
+    eng.L.relmc_debug_schedule(eng._h, out)
+    tuned = getattr(case, "elim_order", None) is not None
+    return {"update_inversion_backsubstitution_passes": [int(out[0]), int(out[1]), int(out[2])], "off_diagonal_blocks": int(out[3]), "tasks": int(out[8]),
+            "elimination_order": "tuned offline against the library's scheduler (relmc_tune_order; the order ships with the package's case)" if tuned
+                                 else "the library's rule (level, then fill)"}
 
 
 def sparse_flop_per_iteration(eng, case):

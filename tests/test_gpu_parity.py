@@ -560,3 +560,30 @@ def test_full_size_properties_1e8_eight_shards(engine):
     ix = dist.indices_from_acc(merged, engine.case.nb, engine.case.ncomp)
     assert 0.00044 < ix["beta"] < 0.00048 and abs(ix["edns"] - 15.197) < 0.02 and abs(ix["plc"] - 0.084969) < 1e-4
     assert 400_000 < db.database_row_count < 700_000
+
+
+@pytest.mark.gpu
+def test_elimination_order_hint_changes_the_schedule_not_the_results(case):
+    """relmc_case_order_hint: the order the package ships for RTS-24 (tuned offline with relmc_tune_order) against the library's rule on the
+    same samples -- every integer accumulator but the iteration sum identical, sums to 1e-9, per-bus nodal sums to 1e-3 (the LP's optimal
+    face is degenerate: an order is a different rounding of the same factorisation), fewer LDS instructions per Newton step; a hint that is
+    not a permutation with the reference bus last is refused by the load and leaves the next load rule-made."""
+    import ctypes as C
+    import dataclasses
+    tuned, rule = api.Engine(case), api.Engine(case, elim_order=None)
+    def sched(e):
+        out = (C.c_int32 * 9)(); e.L.relmc_debug_schedule(e._h, out); return [int(v) for v in out]
+    st, sr = sched(tuned), sched(rule)
+    assert st[0] + st[1] + st[2] <= sr[0] + sr[1] + sr[2] and st != sr
+    n = 200_000
+    a, b = tuned.nsq_accumulate(5, 10**7, n), rule.nsq_accumulate(5, 10**7, n)
+    ai, ad = a.to_arrays(); bi, bd = b.to_arrays()
+    assert np.array_equal(ai[:5], bi[:5]) and np.array_equal(ai[6:], bi[6:]) and abs(int(ai[5]) - int(bi[5])) <= n // 1000
+    np.testing.assert_allclose(ad[:2], bd[:2], rtol=1e-9)
+    np.testing.assert_allclose(ad[2:], bd[2:], rtol=1e-3, atol=1e-3)
+    bad = case.elim_order.copy(); bad[[0, -1]] = bad[[-1, 0]]                      # the reference bus first
+    with pytest.raises(api.RelmcError, match="permutation"):
+        rule.load_case(case, elim_order=bad)
+    rule.load_case(dataclasses.replace(case, elim_order=None))                     # the refused hint is gone: this load is rule-made
+    assert sched(rule) == sr
+    tuned.close(); rule.close()
