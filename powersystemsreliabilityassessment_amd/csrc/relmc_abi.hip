@@ -1341,7 +1341,7 @@ int tune_order_impl(const relmc_case_desc* d, int32_t evaluations, uint64_t seed
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.6 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules + dense pivoted last resort, device state database, multi-rank loop)"; }
+const char* relmc_version(void) { return "relmc 0.7 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules with a tunable elimination order + dense pivoted last resort, device state database, multi-rank loop)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
