@@ -187,8 +187,10 @@ class Engine:
     def load_case(self, case: case24.Case, elim_order="case"):
         """relmc_case_load.  elim_order: the primary elimination order of the solver schedule (external bus numbers, reference bus last:
         relmc_case_order_hint) -- "case" takes `case.elim_order` when the case carries one (the RTS-24 / RTS-96 orders of this package were
-        tuned offline with `tune_order`), None the library's rule."""
+        tuned offline with `tune_order`), None the library's rule, "tune" = run `tune_order` (20000 evaluations, seed 1) right now."""
         holder = _abi.CaseHolder(case)
+        if isinstance(elim_order, str) and elim_order == "tune":          # tune now (host only; ~1-3 ms per evaluation), for a network without a stored order
+            elim_order, _ = tune_order(case, 20000, 1, getattr(case, "elim_order", None))
         order = getattr(case, "elim_order", None) if isinstance(elim_order, str) and elim_order == "case" else elim_order
         if order is not None:
             o = np.ascontiguousarray(order, dtype=np.int32)
