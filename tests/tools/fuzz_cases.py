@@ -9,6 +9,7 @@ m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
 from powersystemsreliabilityassessment_amd import api
 from oracle import coracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
+ORDER = sys.argv[2] if len(sys.argv) > 2 else None           # "tune": every case under an elimination order tuned on the spot (relmc_tune_order)
 rng0 = np.random.default_rng(20261002)
 tot = dict(states=0, status=0, dns=0, it1=0, it2=0, retried=0, dense=0, dense_conv=0, nc_device=0, nc_oracle=0)
 for k in range(n_cases):
@@ -20,7 +21,7 @@ for k in range(n_cases):
     seed = 5000 + k
     try:
         case = m.random_case(np.random.default_rng(seed), nb, chords, ng, lbs, tight, par, pminf)
-        eng = api.Engine(case)
+        eng = api.Engine(case, elim_order=ORDER)
     except Exception as ex:
         print("case %2d nb %3d: not loaded (%s)" % (k, nb, str(ex)[-70:])); continue
     orc = coracle.Oracle(case)
