@@ -24,6 +24,14 @@ namespace relmc {
 
 #define DEVFI __device__ __forceinline__
 
+#ifndef RELMC_PRIO_BIT
+// The first-dispatched wavefronts alternate between the lowest and the highest priority on this bit of the shader clock, sampled at the top of
+// every interior-point iteration (~29 500 clocks on both test systems).  Round 3 sweep (profiles/r3_pf/c37_*.log, c38_*.log; RTS-24 / RTS-96 against
+// bit 15, the round-1 choice): bits 9-11 +1..3 %, 12 -0.9 % / -1.0 %, 13, 14, 16 +1..2 % (a period close to the iteration's: the same wavefront wins
+// iteration after iteration), 18-22 -0.7 % / -0.5 %, a coin per wavefront and iteration (RELMC_PRIO_BIT < 0) +0.4 % / +0.7 %, the iteration's parity +7 %.
+// On top of bit 12: high level 2 instead of 3, or a second evaluation before the Newton step: -0.2 % / +0.2 .. +1 % (c39_*.log), not taken.
+#define RELMC_PRIO_BIT 12
+#endif
 #ifndef RELMC_MIN_WAVES
 #define RELMC_MIN_WAVES 2          // waves per SIMD the register allocator must allow (<= 256 VGPRs)
 #endif
@@ -355,6 +363,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // the TIME.  The work assignment stays static, so results are unchanged and reproducible.
     const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? ((tid >> 8) & 1) == 0 : false);      // mode 2: the waves that came first on their SIMD (0-3; 8-11 behind 4-7)
     if (a.prio_mode != 0 && !prio_first) __builtin_amdgcn_s_setprio(1);
+#if RELMC_PRIO_BIT < 0
+    uint32_t prio_rng = (uint32_t)(blockIdx.x * WPB + (tid >> 6)) * 2654435761u + 12345u;
+#endif
     // Fused non-sequential path on the 16-lane tile: every wavefront owns a contiguous range of scenario groups and walks
     // it in windows of 64 scenarios.  The window's states are sampled up front, one scenario per lane, and ordered so that
     // the states whose unit outages leave less capacity than the load (13-16 interior-point iterations instead of 12) share rows of the same groups: a
@@ -809,7 +820,14 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         PT_MARK(0)
         // ===== mips main loop =======================================
         while (__any(iterating)) {
-            if (prio_first) { if ((__builtin_readcyclecounter() >> 15) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0); }
+            if (prio_first) {
+#if RELMC_PRIO_BIT >= 0
+                if ((__builtin_readcyclecounter() >> RELMC_PRIO_BIT) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#else
+                prio_rng = prio_rng * 1664525u + 1013904223u;                       // A/B: a coin per wavefront and iteration instead of a clock bit
+                if (__builtin_amdgcn_readfirstlane(prio_rng) >> 31) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
+#endif
+            }
             RELOAD_FENCE();
             // The per-slot conditions (slot in service / boxed / owner / pinned ...) are loop invariant, so the compiler hoists them out of the
             // interior-point loop as 64-bit lane masks: ~45 masks, 163 SGPRs spilled to VGPR lanes, and the VGPRs those push out go to scratch.
