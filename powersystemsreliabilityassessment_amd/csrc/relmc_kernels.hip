@@ -133,6 +133,10 @@ DEVFI double frcp(double x)
 #ifndef RELMC_INJ_NFORM
 #define RELMC_INJ_NFORM 1           // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
 #endif
+#ifndef RELMC_INJ_NFORM_WIDE
+#define RELMC_INJ_NFORM_WIDE 0      // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: the gain
+                                    // does not pay for rescanning which states the primary order fails on (tests/golden/rts96_numfail_fixture.json) a second time
+#endif
 #ifndef RELMC_RPAIR_MASK_WIDE
 #define RELMC_RPAIR_MASK_WIDE 0     // 64-lane tile
 #endif
@@ -879,7 +883,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const d2 hl = IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
                         const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
-                        if constexpr (RW == 16 && RELMC_INJ_NFORM) {
+                        if constexpr ((RW == 16 && RELMC_INJ_NFORM) || (RW == 64 && RELMC_INJ_NFORM_WIDE)) {
                             // D = N / (z+ z-) with N = mu+ z- + mu- z+: 1/D and Np/D from ONE reciprocal (of N) instead of three (round 3: -1.9 %
                             // kernel time; no fixture state changes its iteration count, 6 of 1e6 sampled scenarios do by one).  The 64-lane tile keeps
                             // its round-2 arithmetic (see RELMC_RPAIR_MASK_WIDE).
