@@ -134,8 +134,8 @@ DEVFI double frcp(double x)
 #define RELMC_INJ_NFORM 1           // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
 #endif
 #ifndef RELMC_INJ_NFORM_WIDE
-#define RELMC_INJ_NFORM_WIDE 0      // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: the gain
-                                    // does not pay for rescanning which states the primary order fails on (tests/golden/rts96_numfail_fixture.json) a second time
+#define RELMC_INJ_NFORM_WIDE 0      // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: with either, one of the
+                                    // 317 RTS-96 fixture states ends 6 iterations away from the C oracle (17 -> 23; the pin is +-1 on every state), tried and reverted
 #endif
 #ifndef RELMC_RPAIR_MASK_WIDE
 #define RELMC_RPAIR_MASK_WIDE 0     // 64-lane tile
