@@ -116,7 +116,7 @@ def test_tune_order_is_deterministic_never_worse_and_validated():
 def test_shipped_rts24_order_is_what_the_tuner_returns():
     """Provenance of case24.RTS24_ELIM_ORDER: relmc_tune_order(60000 evaluations, seed 11) from the rule's order, bit for bit (the tuner is
     deterministic; a change of the scheduler or of its cost model shows up here, and the shipped orders are then due for a new tuning and a
-    new run of scripts/order_select.py against the parity pins)."""
+    new run of tests/tools/order_select.py against the parity pins)."""
     from powersystemsreliabilityassessment_amd import api
     case = case24.rts24()
     order, st = api.tune_order(case, 60000, seed=11)

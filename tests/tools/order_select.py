@@ -1,8 +1,8 @@
 """Which of the tuned candidate orders keep the parity pins?  For every order file: kernel ms per 1e6, fixture states whose iteration count
 moves, and the per-bus nodal sums of 3e5 sampled states against the C oracle (developer tool; uses the oracle, hence lives with the
-gpurun command files and is not part of the product):  python scripts/order_select.py rts24 <order files...>"""
+developer tools under tests/ and is not part of the product):  python tests/tools/order_select.py rts24 <order files...>"""
 import json, os, sys
-ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__))); sys.path.insert(0, ROOT)
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__)))); sys.path.insert(0, ROOT)
 import numpy as np
 from powersystemsreliabilityassessment_amd import api, case24, case96
 from oracle import coracle
