@@ -342,7 +342,7 @@ int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t pro
 /* The primary order as a tunable of the schedule.  The Newton step of every scenario runs a static pass program that relmc_case_load
  * derives from the elimination order of the buses (MATLAB's `\` under mips picks its own pivot order per call, mc_simulation.m:41); the
  * built-in rule (shallow elimination tree first, then little fill) is good, an order searched against the scheduler itself is better:
- * RTS-24 174 -> 168 LDS instructions per Newton step (-1.5 % kernel time), RTS-96 215 -> 201 and 32 -> 29 dependent passes (-3.1 %).
+ * RTS-24 174 -> 168 LDS instructions per Newton step (-1.4 % kernel time), RTS-96 215 -> 200 and 32 -> 28 dependent passes (-2.9 %).
  *   relmc_tune_order       host only (no device, no context): simulated annealing over bus permutations, `evaluations` runs of the scheduler
  *                          (3 ms each on RTS-96), deterministic in `seed`; start = NULL begins at the rule's order.  order_out[nb] = external
  *                          bus numbers in elimination order, the reference bus last; stats_out (optional) = {LDS instructions per Newton step,
