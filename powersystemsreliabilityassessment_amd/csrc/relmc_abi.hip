@@ -2382,7 +2382,7 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         }
         cp++;
     };
-    constexpr int64_t kStretch = 1 << 18, kStretchMaxBatch = 8192;
+    constexpr int64_t kStretch = 1 << 18, kStretchMaxBatch = 32768;
     // More than one rank (relmc_comm_init / relmc_comm_set_host_allreduce): every batch [done, done + m) of the global sample stream is split
     // contiguously over the ranks, each evaluates its slice, ONE all-reduce of the accumulators per batch (the convergence check), and every
     // rank computes the same indices and stops at the same batch -- the parfor of nsqMain.m:257-263 with the loop around it, so that a C,
@@ -2419,8 +2419,8 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     // sums and the loss count) follow on the host.  If beta reaches its limit inside the stretch, the stretch is cut at that
     // checkpoint and taken again over the shorter range (the database is first put back to its rows and counts of before
     // the stretch), so that the result is the one of the batch-by-batch loop.  Only for batches whose launch is overhead-bound (a launch
-    // costs 0.2-0.4 ms whatever its size, i.e. as much as 1e4 scenarios), and with stretches that grow with the samples already drawn
-    // (256 batches at first, then as many samples as the run holds, up to 2^18): what a cut throws away stays in proportion to the run.
+    // costs 0.2-0.4 ms whatever its size, i.e. as much as 1e4 scenarios), and with stretches sized from the run's own beta (below; up to 2^18
+    // samples each): what a cut throws away stays a few per cent of the run.
     if ((o->distinct_states == 0 || o->distinct_states == 2) && o->batch <= kStretchMaxBatch &&
         !std::getenv("RELMC_NSQ_NO_STRETCH") /* diagnosis: one launch per batch */) {
         const bool use_db = o->distinct_states == 2;
@@ -2436,7 +2436,19 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
         }
         const double* const hd = ctx->hhist;
         while (beta > o->beta_limit && done < o->max_samples) {
-            int64_t len = done > 256 * o->batch ? done / o->batch * o->batch : 256 * o->batch;
+            // How long a stretch?  beta falls like 1 / sqrt(n), so the run will need about done * (beta / limit)^2 samples: go to 90 % of that in
+            // one stretch, then to 103 % of the (then better) prediction -- a stretch that is cut is taken again over its used part, so the last one
+            // should be short (round 3: beta < 1 % at the reference's batch of 100 in 5.9 instead of 9.4 ms; doubling stretches evaluated 416 k
+            // samples for a run of 211 k).  Without a prediction (first stretch, no loss yet, limit 0): ~25 600 samples, then as many as the run holds.
+            const int64_t first = 25600 / o->batch > 0 ? 25600 / o->batch * o->batch : o->batch;      // ~25 600 samples, whole batches
+            const int64_t least = 1600 / o->batch > 0 ? 1600 / o->batch * o->batch : o->batch;
+            int64_t len = done > first ? done / o->batch * o->batch : first;
+            if (done > 0 && o->beta_limit > 0.0 && beta < 1e6 && beta > o->beta_limit) {
+                const double need = (double)done * (beta / o->beta_limit) * (beta / o->beta_limit);
+                const double target = (double)done < 0.85 * need ? 0.9 * need : 1.03 * need;
+                const double l = std::ceil((target - (double)done) / (double)o->batch) * (double)o->batch;
+                len = l < (double)least ? least : (l > (double)per ? per : (int64_t)l);
+            }
             if (len > per) len = per;
             const int64_t m = (o->max_samples - done) < len ? (o->max_samples - done) : len;
             relmc_acc part;
