@@ -29,6 +29,10 @@ static_assert(sizeof(DevAcc) == sizeof(relmc_acc), "device accumulator image mus
 
 struct relmc_ctx {
     int device = -1;
+    // relmc_seq_years' device buffers, kept between calls (six hipMalloc / hipFree pairs per call were 1 ms of a 17 ms step): grow-only
+    uint32_t* sq_dm = nullptr; size_t sq_dm_words = 0;
+    uint16_t* sq_hours = nullptr; double* sq_curt = nullptr; size_t sq_nh = 0;
+    uint32_t* sq_counts = nullptr; uint32_t* sq_off = nullptr; double* sq_year = nullptr; int sq_years = 0;
     std::vector<int32_t> order_hint;     // relmc_case_order_hint: primary elimination order of the next relmc_case_load (external bus numbers), empty = the rule
     int place_moves = -1;                // >= 0: overrides the placement-search length (the order tuner runs the scheduler without it)
     hipStream_t stream = nullptr;
@@ -1381,6 +1385,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dacc) (void)hipFree(ctx->dacc);
     if (ctx->dhl1) (void)hipFree(ctx->dhl1);
     if (ctx->dseq) (void)hipFree(ctx->dseq);
+    for (void* q : {(void*)ctx->sq_dm, (void*)ctx->sq_hours, (void*)ctx->sq_curt, (void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year}) if (q) (void)hipFree(q);
     if (ctx->dlf) (void)hipFree(ctx->dlf);
     if (ctx->dsorted) (void)hipFree(ctx->dsorted);
     if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
@@ -2187,15 +2192,17 @@ int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, i
 
 namespace {
 // chronology of years [first_year, first_year + n_years) into freshly zeroed device masks
+// *dmasks_out == nullptr on entry: a buffer is allocated for the caller (who frees it); otherwise the masks go into the caller's buffer
 int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, uint32_t** dmasks_out)
 {
     const size_t words = (size_t)n_years * ctx->hseq.hpy * ctx->hseq.mw;
-    uint32_t* dm = nullptr;
-    HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
-    if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
+    const bool own = *dmasks_out == nullptr;
+    uint32_t* dm = *dmasks_out;
+    if (own) HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
+    if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
     const int64_t nthr = (int64_t)n_years * ctx->hseq.ncomp;
     hipLaunchKernelGGL(relmc_seq_sampling_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dseq, seed, first_year, n_years, dm);
-    if (hipGetLastError() != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: sampling launch failed"); }
+    if (hipGetLastError() != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: sampling launch failed"); }
     *dmasks_out = dm;
     return RELMC_OK;
 }
@@ -2247,14 +2254,26 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     relmc_solver_opts o;
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
     const int hpy = ctx->hseq.hpy;
-    uint32_t* dm = nullptr; uint16_t* dhours = nullptr; uint32_t* dcounts = nullptr; uint32_t* doff = nullptr; double* dcurt = nullptr; double* dyear = nullptr;
-    auto cleanup = [&]() { (void)hipFree(dm); (void)hipFree(dhours); (void)hipFree(dcounts); (void)hipFree(doff); (void)hipFree(dcurt); (void)hipFree(dyear); };
+    // the device buffers of a step live in the context and only ever grow
+    const size_t nh = (size_t)n_years * hpy, words = nh * (size_t)ctx->hseq.mw;
+    bool alloc_ok = true;
+    if (ctx->sq_dm_words < words) { if (ctx->sq_dm) (void)hipFree(ctx->sq_dm); ctx->sq_dm = nullptr; ctx->sq_dm_words = 0;
+                                    alloc_ok = hipMalloc(&ctx->sq_dm, words * sizeof(uint32_t)) == hipSuccess; if (alloc_ok) ctx->sq_dm_words = words; }
+    if (alloc_ok && ctx->sq_nh < nh) { if (ctx->sq_hours) (void)hipFree(ctx->sq_hours); if (ctx->sq_curt) (void)hipFree(ctx->sq_curt); ctx->sq_hours = nullptr; ctx->sq_curt = nullptr; ctx->sq_nh = 0;
+                                       alloc_ok = hipMalloc(&ctx->sq_hours, nh * sizeof(uint16_t)) == hipSuccess && hipMalloc(&ctx->sq_curt, nh * sizeof(double)) == hipSuccess; if (alloc_ok) ctx->sq_nh = nh; }
+    if (alloc_ok && ctx->sq_years < n_years) {
+        for (void* q : {(void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year}) if (q) (void)hipFree(q);
+        ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr; ctx->sq_years = 0;
+        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * n_years) == hipSuccess && hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
+                   hipMalloc(&ctx->sq_year, sizeof(double) * 3 * n_years) == hipSuccess;
+        if (alloc_ok) ctx->sq_years = n_years;
+    }
+    if (!alloc_ok) return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: device allocation failed");
+    uint32_t* dm = ctx->sq_dm; uint16_t* const dhours = ctx->sq_hours; uint32_t* const dcounts = ctx->sq_counts; uint32_t* const doff = ctx->sq_off;
+    double* const dcurt = ctx->sq_curt; double* const dyear = ctx->sq_year;
+    auto cleanup = [&]() {};
     int rc = seq_sample(ctx, seed, first_year, n_years, &dm);
     if (rc) return rc;
-    const size_t nh = (size_t)n_years * hpy;
-    if (hipMalloc(&dhours, nh * sizeof(uint16_t)) != hipSuccess || hipMalloc(&dcounts, sizeof(uint32_t) * n_years) != hipSuccess ||
-        hipMalloc(&doff, sizeof(uint32_t) * (n_years + 1)) != hipSuccess || hipMalloc(&dcurt, nh * sizeof(double)) != hipSuccess ||
-        hipMalloc(&dyear, sizeof(double) * 3 * n_years) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: device allocation failed"); }
     std::vector<uint32_t> counts(n_years), off(n_years + 1, 0);
     bool ok = hipMemsetAsync(dcurt, 0, nh * sizeof(double), ctx->stream) == hipSuccess;
     hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, ctx->hseq.mw, dhours, dcounts);
