@@ -543,6 +543,55 @@ def test_converged_run_vs_golden_within_its_standard_errors(engine, golden):
     assert len(lines) == 100 and lines[-1].startswith("Iteration 100000: Beta = 0.0145")
 
 
+def test_nsq_golden_joint_pin(engine, golden, capsys):
+    """The reference's golden NSQ run as ONE draw of its 17-bus nodal-EENS vector, of its importance vector and of (EDNS, PLC): Mahalanobis
+    distances from the converged device means with the EXACT per-sample covariances of the device's state database rows, scaled to the
+    golden run's N = 1e5 (nsqMain.m:348-349, 366-376, 286-296; tests/golden_stats.py).  REFERENCE_EMULATE must lie inside the 99 % region
+    of all three; PHYSICAL (isolated-bus states solved island-aware instead of MIPS' consumed start point) is REJECTED by
+    the nodal and the importance vectors -- which is the proof that the pin can see what separates the two policies.
+    Measured (profiles/r4_final/golden_pin.log): emulate p = 0.24 / 0.67 / 0.41; physical p = 5e-118 / 1e-7 / 0.07."""
+    import golden_stats as gs
+    case = engine.case
+    res = {}
+    for name, pol in (("emulate", api.REFERENCE_EMULATE), ("physical", api.PHYSICAL)):
+        r = engine.nsqMain(beta_limit=0.0, max_iterations=20_000_000, samples_per_batch=2_000_000, seed=1, distinct_states="database", mpopt=api.mpoption(pol))
+        assert r.current_iteration == 20_000_000 and r.n_nonconverged == 0
+        res[name] = gs.nsq_joint_pin(engine.db_export(), golden, case.bus_pd > 0, case.always_up)
+        engine.db_reset()
+    with capsys.disabled():
+        for name in res:
+            print("\n   golden NSQ run vs %s:" % name, ", ".join("%s T = %.2f chi2(%d) p = %.3g" % (k, o["T"], o["dof"], o["p"]) for k, o in res[name].items()), end="")
+    e, ph = res["emulate"], res["physical"]
+    assert e["nodal"]["dof"] == 17 and e["edns_plc"]["dof"] == 2 and e["importance"]["dof"] >= 40
+    assert e["nodal"]["p"] > 0.01 and e["importance"]["p"] > 0.01 and e["edns_plc"]["p"] > 0.01
+    assert ph["nodal"]["p"] < 1e-9 and ph["importance"]["p"] < 1e-3          # the policy the reference does NOT follow is told apart
+    np.testing.assert_allclose(e["nodal"]["mean"][case.bus_pd == 0], 0.0, atol=0)
+
+
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_sampled_state_contract_2e5(engine, oracle, policy):
+    """The numerical contract of the shipped arithmetic on SAMPLED states, not only on the fixtures: the first 2e5 samples of seed 1, device
+    against the C oracle, state by state -- status identical, |dns difference| <= 1e-6 MW, IPM iteration counts equal but for +-1 on fewer
+    than 0.1 % of the states and nothing beyond, per-bus nodal sums to 1e-3 (round 3 kept this as a builder-run log over 1e6 / 5e6 samples,
+    profiles/r3_final/sampled_vs_oracle_rts24.log: 0 / 0 / 0.0085 % / 0)."""
+    n, ch = 200_000, 100_000
+    dev_n = np.zeros(engine.case.nb); orc_n = np.zeros(engine.case.nb)
+    it1 = it2 = 0
+    for lo in range(0, n, ch):
+        st = engine.mc_sampling(None, ch, seed=1, first_index=lo)
+        dns, nodal, info = engine.mc_simulation(st, mpopt=api.mpoption(policy), return_info=True)
+        ref = oracle.mc_simulation(st, policy, nthreads=16)
+        assert np.array_equal(info["status"], ref["status"])
+        assert np.abs(dns - ref["dns"]).max() <= DNS_TOL
+        di = np.abs(info["iters"] - ref["iters"])
+        it1 += int((di == 1).sum()); it2 += int((di > 1).sum())
+        dev_n += nodal.sum(0); orc_n += ref["nodal"].sum(0)
+    assert it2 == 0 and it1 < n // 1000
+    m = orc_n > 0
+    np.testing.assert_allclose(dev_n[m], orc_n[m], rtol=1e-3)
+    assert np.all(dev_n[~m] == 0)
+
+
 def test_full_size_properties_1e8_eight_shards(engine):
     """BASELINE configs[2] size (1e8 samples over 8 shards) on the one GPU of the box: the eight shards' accumulators merged the way
     the all-reduce merges them == the state database fed with the same 1e8 samples (two entirely different routes: every sample
