@@ -26,14 +26,8 @@ struct TileT {
     static constexpr int WPB = WPB_;           // wavefronts per workgroup (they share the case tables)
     static_assert(BS_ <= 2 && LS_ <= 3 && IS_ <= 4, "the per-lane flag word has room for 2 bus, 3 line and 4 injection slots");
 };
-#ifndef RELMC_T24_IS
-#define RELMC_T24_IS 4             // injection slots of the 16-lane tile (3 = ablation: what would a 48-injection RTS-24 cost?)
-#endif
-using Tile24 = TileT<16, 2, 3, RELMC_T24_IS, 128, 96, 160, 4>;
-#ifndef RELMC_T96_WPB
-#define RELMC_T96_WPB 8
-#endif
-using Tile96 = TileT<64, 2, 2, 3, 256, 64, 320, RELMC_T96_WPB>;
+using Tile24 = TileT<16, 2, 3, 4, 128, 96, 160, 4>;
+using Tile96 = TileT<64, 2, 2, 3, 256, 64, 320, 8>;
 constexpr int DEGMAX = 8;          // lines per bus
 constexpr int BINJMAX = 8;         // injections per bus
 

@@ -24,17 +24,13 @@ namespace relmc {
 
 #define DEVFI __device__ __forceinline__
 
-#ifndef RELMC_PRIO_BIT
 // The first-dispatched wavefronts alternate between the lowest and the highest priority on this bit of the shader clock, sampled at the top of
 // every interior-point iteration (~29 500 clocks on both test systems).  Round 3 sweep (profiles/r3_pf/c37_*.log, c38_*.log; RTS-24 / RTS-96 against
 // bit 15, the round-1 choice): bits 9-11 +1..3 %, 12 -0.9 % / -1.0 %, 13, 14, 16 +1..2 % (a period close to the iteration's: the same wavefront wins
-// iteration after iteration), 18-22 -0.7 % / -0.5 %, a coin per wavefront and iteration (RELMC_PRIO_BIT < 0) +0.4 % / +0.7 %, the iteration's parity +7 %.
+// iteration after iteration), 18-22 -0.7 % / -0.5 %, a coin per wavefront and iteration +0.4 % / +0.7 %, the iteration's parity +7 %.
 // On top of bit 12: high level 2 instead of 3, or a second evaluation before the Newton step: -0.2 % / +0.2 .. +1 % (c39_*.log), not taken.
-#define RELMC_PRIO_BIT 12
-#endif
-#ifndef RELMC_MIN_WAVES
-#define RELMC_MIN_WAVES 2          // waves per SIMD the register allocator must allow (<= 256 VGPRs)
-#endif
+constexpr int kPrioBit = 12;
+constexpr int kMinWaves = 2;       // waves per SIMD the register allocator must allow (<= 256 VGPRs)
 
 template <int CTRL>
 DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
@@ -126,20 +122,12 @@ DEVFI double frcp(double x)
 // lines' ratio tests, both updates -- under which every one of the 878 + 317 fixture states keeps its iteration count and 8 of 1e6 sampled
 // scenarios change theirs by one (-1.2 % kernel time).  On the 64-lane tile the same mask is 1.5 % SLOWER (the wide tile is bound by its chain, and
 // the pair form is one multiplication longer) and moves which RTS-96 states the primary order fails on, which the retry tests pin: it stays at the
-// round-2 arithmetic, bit for bit.  -DRELMC_RPAIR_MASK=0 gives that on both tiles, 0xff all sites.
-#ifndef RELMC_RPAIR_MASK
-#define RELMC_RPAIR_MASK 0xCD       // 16-lane tile.  bit 0 / 1 evaluation lines / injections, 2 / 4 ratio-test slacks (lines / injections), 3 / 5 ratio-test multipliers, 6 / 7 update lines / injections
-#endif
-#ifndef RELMC_INJ_NFORM
-#define RELMC_INJ_NFORM 1           // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
-#endif
-#ifndef RELMC_INJ_NFORM_WIDE
-#define RELMC_INJ_NFORM_WIDE 0      // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: with either, one of the
+// round-2 arithmetic, bit for bit.  Mask 0 gives that on both tiles, 0xff all sites.
+constexpr int kRpairMask = 0xCD;     // 16-lane tile.  bit 0 / 1 evaluation lines / injections, 2 / 4 ratio-test slacks (lines / injections), 3 / 5 ratio-test multipliers, 6 / 7 update lines / injections
+constexpr int kInjNform = 1;         // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
+constexpr int kInjNformWide = 0;     // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: with either, one of the
                                     // 317 RTS-96 fixture states ends 6 iterations away from the C oracle (17 -> 23; the pin is +-1 on every state), tried and reverted
-#endif
-#ifndef RELMC_RPAIR_MASK_WIDE
-#define RELMC_RPAIR_MASK_WIDE 0     // 64-lane tile
-#endif
+constexpr int kRpairMaskWide = 0;    // 64-lane tile
 template <bool PAIR>
 DEVFI void frcp_pair(double a, double b, double& ra, double& rb)
 {
@@ -198,18 +186,14 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 #define SLOT_FENCE() __builtin_amdgcn_sched_barrier(0)
 // (round 3 re-measured every one of the six fence sites: removing any of them is neutral on the 16-lane tile and 0.3-2.7 % slower on the
 // wide one, profiles/r3_pf/c11_*.log)
-// LDS round trips of the vector phases taken off the wavefront's critical path (RELMC_PF_MASK, bit k = site k): table words are requested
+// LDS round trips of the vector phases taken off the wavefront's critical path (kPfMask, bit k = site k): table words are requested
 // before the work that hides their latency instead of right where they are used.  Same arithmetic.
 //   1 assembly: block offsets before the gathers                       2 gathers: incidence lists of both bus slots up front
 //   3 step: the lines' and injections' solution entries as one batch   6 / 7 step / convergence test: solver options requested before the row reductions
 // (sites 0, 4, 5 -- injection bounds / cost / lambda one slot ahead in the evaluation, the ratio tests, the update -- were measured neutral
 //  to +1.8 % on both tiles and are gone from the source: profiles/r3_pf/c13_*.log)
-#ifndef RELMC_PF_MASK
-#define RELMC_PF_MASK 0xc0          // 16-lane tile: sites 6, 7 (-1 % kernel time; site 3 on top: -0.3 % for +44 B/lane of scratch = +40 % HBM traffic, not taken; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
-#endif
-#ifndef RELMC_PF_MASK_WIDE
-#define RELMC_PF_MASK_WIDE 0xc6     // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
-#endif
+constexpr int kPfMask = 0xc0;        // 16-lane tile: sites 6, 7 (-1 % kernel time; site 3 on top: -0.3 % for +44 B/lane of scratch = +40 % HBM traffic, not taken; single sites -0.3 .. +1.3 %, profiles/r3_pf/)
+constexpr int kPfMaskWide = 0xc6;    // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
 #define PFSITE(k) (((PF_MASK >> (k)) & 1) != 0)
 // optional per-phase cycle accounting (profiling builds only: -DRELMC_PHASE_TIMING)
 #ifdef RELMC_PHASE_TIMING
@@ -243,16 +227,16 @@ DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinter
 //         the row's key words, results written into the row (dns, status/iterations, nodal shed); no accumulation
 // MODE 6: MODE 4 with a dense, partially pivoted Newton solve in global scratch (a.dense): the last resort of the retry path
 template <int MODE_, class TL>
-__global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
+__global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
     constexpr int MODE = MODE_ == 5 ? 0 : (MODE_ == 6 ? 4 : MODE_);     // 5: the order-calibration probe = the fused path under a kernel name of its own (profiles stay clean)
     // MODE 6: MODE 4's rows with the Newton step solved DENSE with partial pivoting (the last resort for the units no static elimination
     // order converges on: MATLAB's `\` under mips, mc_simulation.m:41, pivots too).  The reduced system of order 2 nb lives in a global
     // scratch matrix per scenario row (RTS-96: 146 x 147 doubles do not fit LDS beside the tables); slow and rare by construction.
     constexpr bool DENSE = MODE_ == 6;
-    constexpr int PAIR_MASK = TL::RW == 16 ? RELMC_RPAIR_MASK : RELMC_RPAIR_MASK_WIDE;      // which call sites share a reciprocal (frcp_pair)
+    constexpr int PAIR_MASK = TL::RW == 16 ? kRpairMask : kRpairMaskWide;      // which call sites share a reciprocal (frcp_pair)
 #define PAIRSITE(k) (((PAIR_MASK >> (k)) & 1) != 0)
-    constexpr int PF_MASK = TL::RW == 16 ? RELMC_PF_MASK : RELMC_PF_MASK_WIDE;                 // which LDS round trips are taken off the critical path (PFSITE)
+    constexpr int PF_MASK = TL::RW == 16 ? kPfMask : kPfMaskWide;                 // which LDS round trips are taken off the critical path (PFSITE)
     constexpr int RW = TL::RW, BS = TL::BS, LS = TL::LS, IS = TL::IS, NBT = TL::NBT, WPB = TL::WPB, SPW = TL::SPW, OW = TL::OW;
     using DevCase = DevCaseT<TL>;
     using Partial = PartialT<TL>;
@@ -311,16 +295,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // injection bounds on the wide tile (-1.8 %; +0.6 % on the narrow one).  Cost and incidence lists in registers: neutral / +14 %.
     // ... per instantiation: the instantiations that write per-scenario results or walk the chronology (MODE 1, 2, 4) carry more live state
     // and lose 2-3 % with the line values in registers (measured on MODE 1 and 2), the fused ones gain 1-2 %
-#ifdef RELMC_LTAB_LDS_ALL      // A/B of the scratch traffic (profiles/r3_final/scratch_ab.log): every instantiation reads the line values from LDS
-    constexpr bool LTAB_LDS = true;
-#else
+    // (A/Bs of round 3, DESIGN_HISTORY.md: every instantiation reading the line values from LDS halves the scratch traffic at the same time;
+    //  the wide tile reading the injection bounds from the table does not buy a third wavefront per SIMD)
     constexpr bool LTAB_LDS = (MODE == 1 || MODE == 2 || MODE == 4);
-#endif
-#ifdef RELMC_ITAB_MEM          // A/B: the wide tile reads the injection bounds from the table too (register diet for a third wave per SIMD)
-    constexpr bool ITAB_REG = false;
-#else
     constexpr bool ITAB_REG = RW == 64;
-#endif
     double lbv_[LS], lrv_[LS], ihi_[IS], ilo_[IS];
 #pragma unroll
     for (int s = 0; s < LS; ++s) { lbv_[s] = LTAB_LDS ? 0.0 : TABL.l_b[RW * s + rlane]; lrv_[s] = LTAB_LDS ? 0.0 : TABL.l_rate[RW * s + rlane]; }
@@ -367,9 +345,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
     // the TIME.  The work assignment stays static, so results are unchanged and reproducible.
     const bool prio_first = a.prio_mode == 1 ? blockIdx.x < (gridDim.x >> 1) : (a.prio_mode == 2 ? ((tid >> 8) & 1) == 0 : false);      // mode 2: the waves that came first on their SIMD (0-3; 8-11 behind 4-7)
     if (a.prio_mode != 0 && !prio_first) __builtin_amdgcn_s_setprio(1);
-#if RELMC_PRIO_BIT < 0
-    uint32_t prio_rng = (uint32_t)(blockIdx.x * WPB + (tid >> 6)) * 2654435761u + 12345u;
-#endif
     // Fused non-sequential path on the 16-lane tile: every wavefront owns a contiguous range of scenario groups and walks
     // it in windows of 64 scenarios.  The window's states are sampled up front, one scenario per lane, and ordered so that
     // the states whose unit outages leave less capacity than the load (13-16 interior-point iterations instead of 12) share rows of the same groups: a
@@ -825,12 +800,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
         // ===== mips main loop =======================================
         while (__any(iterating)) {
             if (prio_first) {
-#if RELMC_PRIO_BIT >= 0
-                if ((__builtin_readcyclecounter() >> RELMC_PRIO_BIT) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#else
-                prio_rng = prio_rng * 1664525u + 1013904223u;                       // A/B: a coin per wavefront and iteration instead of a clock bit
-                if (__builtin_amdgcn_readfirstlane(prio_rng) >> 31) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
-#endif
+                if ((__builtin_readcyclecounter() >> kPrioBit) & 1ull) __builtin_amdgcn_s_setprio(3); else __builtin_amdgcn_s_setprio(0);
             }
             RELOAD_FENCE();
             // The per-slot conditions (slot in service / boxed / owner / pinned ...) are loop invariant, so the compiler hoists them out of the
@@ -883,10 +853,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const d2 hl = IHL(s, j);               // {upper, lower} bound
                         const double hp = pv - hl.x, hm = ILOV(s, hl.y) - pv;
                         const double lxp = ICOST(s, j) - Lam[iinfo[s] & 0xff] + (imup[s] - imum[s]);
-                        if constexpr ((RW == 16 && RELMC_INJ_NFORM) || (RW == 64 && RELMC_INJ_NFORM_WIDE)) {
+                        if constexpr ((RW == 16 && kInjNform) || (RW == 64 && kInjNformWide)) {
                             // D = N / (z+ z-) with N = mu+ z- + mu- z+: 1/D and Np/D from ONE reciprocal (of N) instead of three (round 3: -1.9 %
                             // kernel time; no fixture state changes its iteration count, 6 of 1e6 sampled scenarios do by one).  The 64-lane tile keeps
-                            // its round-2 arithmetic (see RELMC_RPAIR_MASK_WIDE).
+                            // its round-2 arithmetic (see kRpairMaskWide).
                             const double N = __builtin_fma(imup[s], izm[s], imum[s] * izp[s]);
                             const double rN = frcp(N), zz = izp[s] * izm[s];
                             invD = zz * rN;
@@ -1068,14 +1038,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     // feascond < feastol, gradcond < gradtol with the (positive) denominators multiplied out
                     conv = conv && mx_gh < A_(0, feastol) * (1.0 + vmax(mx_x, mx_z)) && mx_lx < A_(1, gradtol) * (1.0 + mx_lammu);
                 }
-#ifdef RELMC_ABLATE_FIXIT
-                if (it >= RELMC_ABLATE_FIXIT) { status = 0; iterating = false; }     // profiling only: fixed trip count, no other exit
-                (void)conv; (void)xnan;
-#else
                 if (conv) { status = 0; iterating = false; }
                 else if (it > 0 && (xnan || alphap < (PFSITE(7) ? o_am : A_(7, alpha_min)) || alphad < (PFSITE(7) ? o_am : A_(7, alpha_min)) || gamma < eps || gamma > 1.0 / eps)) { status = 2; iterating = false; }
                 else if (it >= a.max_it) { status = 1; iterating = false; }
-#endif
             }
             PT_MARK(3)
             RELOAD_FENCE();
@@ -1124,7 +1089,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     for (int q = 0; q < (2 * NBT + RW - 1) / RW; ++q) { const int e = rlane + RW * q; if (e < n) W[off_rhs + e] = xs[q]; }
                     RELOAD_FENCE();
                 } else {
-#ifndef RELMC_ABLATE_NO_SOLVE
                 // ---- Newton step: sparse 2x2-block LDL' on the LDS workspace, static schedule --------
                 // descriptors are prefetched one pass ahead (they do not depend on data); 0xffff = no task for this lane
                 // descriptor fields are byte offsets into the scenario's workspace (bit 15 of the first = rhs task in the full-form passes)
@@ -1142,24 +1106,13 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                         const d2 dA = ld2(D); const double dBy = D[3];      // D = [[m, b], [b, -e]]: the second half is needed for -e only (b64 read)
                         const d2 a0 = ld2(Wa), b0 = ld2(Wb), b1 = ld2(Wb + 2);
                         d2 t0 = ld2(T);
-#ifdef RELMC_UPD_ONE_BATCH
-                        // A/B (round 3): all eight operand loads in one batch instead of the second rows after the first row's store -- one LDS round
-                        // trip less per full-form pass, and 0.7 % / 1.5 % SLOWER on RTS-24 / RTS-96 (profiles/r3_pf/c17_*.log): these passes are bound
-                        // by the LDS pipe, not by its latency, and the longer batch holds the pipe against the other wavefronts of the CU.
-                        const d2 a1 = ld2(Wa + 2);
-                        d2 t1 = ld2(T + 2);
-#endif
+                        // (all eight operand loads in one batch -- one LDS round trip less per pass -- is 0.7 % / 1.5 % SLOWER, profiles/r3_pf/c17_*.log:
+                        //  these passes are bound by the LDS pipe, not by its latency, and the longer batch holds the pipe against the CU's other wavefronts)
                         const double pm = dA.x, pb = dA.y, pe = -dBy;
                         const double q = frcp(__builtin_fma(pm, pe, pb * pb));
                         const double P00 = pe * q, P01 = pb * q, P11 = -pm * q;
                         const double g00 = __builtin_fma(a0.x, P00, a0.y * P01), g01 = __builtin_fma(a0.x, P01, a0.y * P11);
                         t0.x -= __builtin_fma(g00, b0.x, g01 * b0.y); t0.y -= __builtin_fma(g00, b1.x, g01 * b1.y);
-#ifdef RELMC_UPD_ONE_BATCH
-                        const double g10 = __builtin_fma(a1.x, P00, a1.y * P01), g11 = __builtin_fma(a1.x, P01, a1.y * P11);
-                        t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
-                        st2(T, t0.x, t0.y);
-                        if (!vec) st2(T + 2, t1.x, t1.y);
-#else
                         st2(T, t0.x, t0.y);
                         if (!vec) {
                             const d2 a1 = ld2(Wa + 2);
@@ -1168,7 +1121,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                             t1.x -= __builtin_fma(g10, b0.x, g11 * b0.y); t1.y -= __builtin_fma(g10, b1.x, g11 * b1.y);
                             st2(T + 2, t1.x, t1.y);
                         }
-#endif
                     }
                     dsc = nxt;
                 }
@@ -1259,7 +1211,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     dsc = nxt;
                 }
                 PT_MARK(5)
-#endif
                 }
                 RELOAD_FENCE();
                 // ---- step lengths ---------------------------------------------------------------------
@@ -1354,11 +1305,7 @@ __global__ void __launch_bounds__(64 * TL::WPB, RELMC_MIN_WAVES) relmc_eval_kern
                     if (it == 1) for (int t = 0; t < BS; ++t) if (vb[t] < nb) (reinterpret_cast<double*>(a.timing) + 512 + 512 * 40)[vb[t]] = (double)C.b_ext[vb[t]];
                 }
 #endif
-#ifdef RELMC_ABLATE_FIXIT
-                if (false) {
-#else
                 if (!(PFSITE(6) ? step2 <= o_ms * o_ms : step2 <= A_(8, max_stepsize) * A_(8, max_stepsize))) {
-#endif
                     // NaN or |dxdlam| > max_stepsize: "numerically failed", x is NOT updated
                     status = 2; iterating = false;
                 } else {
