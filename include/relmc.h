@@ -266,6 +266,17 @@ typedef int32_t (*relmc_allreduce_fn)(void* user, relmc_acc* acc_inout);
 int32_t relmc_comm_set_host_allreduce(relmc_ctx* ctx, int32_t nranks, int32_t rank, relmc_allreduce_fn fn, void* user);
 int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks_out, int32_t* rank_out, int64_t* calls_out,
                         double* seconds_out);
+/* Wall-clock guard.  relmc_comm_init and every collective issued through the context (RCCL or the host's callback) must finish within
+ * `seconds` (default 120; <= 0 switches the guard off): a peer that never arrives cannot be waited out from inside a collective, so on
+ * expiry the rank prints its rank / rank count / pid / device / PCI bus id and what it was waiting for on stderr and ends the process with
+ * exit code 86 -- a multi-GPU job that would hang for the launcher's own timeout becomes a diagnosis within two minutes. */
+int32_t relmc_comm_set_timeout(relmc_ctx* ctx, double seconds);
+/* Sum over the ranks of `count` doubles, in place (same result on every rank).  The sequential loop all-gathers its annual indices with it
+ * (every rank fills its own slots of a zeroed vector: x + 0 + ... + 0 is exact).  RCCL: one ncclAllReduce; a host collective: the
+ * registered relmc_acc all-reduce, 130 doubles per call. */
+int32_t relmc_comm_allreduce_f64(relmc_ctx* ctx, double* buf_inout, int64_t count);
+/* PCI bus id of the GPU the context drives ("0000:c1:00.0", cap >= 16): what a multi-rank host gathers to show its ranks sit on DISTINCT devices */
+int32_t relmc_device_pci_bus_id(const relmc_ctx* ctx, char* out, int32_t cap);
 
 /* ---- estimators (host arithmetic, no device) ---------------------------------------- */
 void relmc_acc_zero(relmc_acc* acc);
@@ -321,8 +332,9 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
 /* Units (samples, states, database rows) that the solver's static elimination order ends non-converged (status MAXIT or NUMFAIL;
  * 6.7e-7 of the RTS-96 scenarios, 4e-10 on RTS-24) are evaluated again under further static orders by every entry point, the
  * sequential ones included; the later attempt's results replace the first's.  Counters since relmc_case_load:
- * units re-evaluated, and how many of them ended converged (or MATPOWER-singular).  RELMC_NO_RETRY=1 in the environment turns the
- * second attempt off (diagnosis). */
+ * units re-evaluated, and how many of them ended converged (or MATPOWER-singular).  (The library reads ONE environment variable, RELMC_VERBOSE:
+ * schedule statistics on stderr.  Diagnosis switches -- no second attempt, dense level first, one launch per batch -- exist as test hooks
+ * only, relmc_debug_set in csrc/relmc_debug.hip.) */
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);
 /* The kernel's list of non-converged units holds 4096 + (units of the call) / 256 entries.  relmc_nsq_accumulate / relmc_nsq_run
  * (every sample solved) evaluate a chunk again with a longer list if it overflows; the other entry points leave the units beyond the
@@ -361,7 +373,7 @@ int32_t relmc_case_order_hint(relmc_ctx* ctx, const int32_t* order, int32_t n);
  * (the last checkpoint of a stretch, and with it the result, from the device accumulators themselves), which differ from the
  * batch-by-batch device sums in the last bits; integers (samples, loss counts, the stopping batch on any beta not within 1e-12 of its
  * limit) are identical.  A stretch that is cut at the stopping batch is evaluated again over the shorter range; its first evaluation
- * leaves no trace in relmc_retry_stats or kernel_seconds.  RELMC_NSQ_NO_STRETCH=1 forces one launch per batch (diagnosis). */
+ * leaves no trace in relmc_retry_stats or kernel_seconds.  */
 int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* opts, relmc_nsq_result* result);
 
 #ifdef __cplusplus

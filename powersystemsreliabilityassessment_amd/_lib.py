@@ -27,6 +27,7 @@ EXPORTS = [
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_retry_dense_stats", "relmc_case_order",
     "relmc_case_order_hint", "relmc_tune_order",
+    "relmc_comm_set_timeout", "relmc_comm_allreduce_f64", "relmc_device_pci_bus_id",
 ]
 
 
@@ -115,6 +116,12 @@ def load():
     L.relmc_comm_set_host_allreduce.restype = C.c_int32
     L.relmc_comm_info.argtypes = [vp, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int64_p, _abi.c_double_p]
     L.relmc_comm_info.restype = C.c_int32
+    L.relmc_comm_set_timeout.argtypes = [vp, C.c_double]
+    L.relmc_comm_set_timeout.restype = C.c_int32
+    L.relmc_comm_allreduce_f64.argtypes = [vp, dp, C.c_int64]
+    L.relmc_comm_allreduce_f64.restype = C.c_int32
+    L.relmc_device_pci_bus_id.argtypes = [vp, C.c_char_p, C.c_int32]
+    L.relmc_device_pci_bus_id.restype = C.c_int32
     L.relmc_db_reset.argtypes = [vp]
     L.relmc_db_reset.restype = C.c_int32
     L.relmc_nsq_db_batch.argtypes = [vp, C.c_uint64, C.c_uint64, C.c_int64, C.POINTER(_abi.SolverOpts), C.POINTER(_abi.Acc),
@@ -143,6 +150,9 @@ def load():
     L.relmc_db_export.restype = C.c_int32
     L.relmc_db_import.argtypes = [vp, C.c_void_p, C.c_int64, u8p, _abi.c_int64_p, dp, dp, i32p, i32p, u8p]
     L.relmc_db_import.restype = C.c_int32
+    if hasattr(L, "relmc_debug_set"):
+        L.relmc_debug_set.argtypes = [vp, C.c_char_p, C.c_int32]
+        L.relmc_debug_set.restype = C.c_int32
     if hasattr(L, "relmc_dpp_probe"):
         L.relmc_dpp_probe.argtypes = [vp, dp, dp]
         L.relmc_dpp_probe.restype = C.c_int32

@@ -151,7 +151,7 @@ struct EvalArgs {
     // results go to dns[row], status[row] (packed) and nodal[row][nb]
     int64_t db_first;
     // Units (samples / states / rows) that end non-converged (status 1 or 2) are listed here instead of being accumulated; the host
-    // evaluates them again under further elimination orders (relmc_abi.hip: fail_retry).  Null = off.
+    // evaluates them again under further elimination orders (relmc_retry.hip: fail_retry).  Null = off.
     uint32_t* fail_count;
     FailRec* fail_list;
     uint32_t fail_cap;
@@ -160,5 +160,29 @@ struct EvalArgs {
     double* dense;
     uint64_t dense_stride;
 };
+
+// device image of relmc_acc (include/relmc.h): 6 + 256 int64, then 2 + 128 doubles
+struct DevAcc {
+    long long n, n_fail, n_singular, n_infeasible, n_nonconverged, sum_iters;
+    long long comp_fail[256];
+    double sum_dns, sum_dns2;
+    double sum_nodal[128];
+};
+
+constexpr int FIN_ITEMS = 8 + 256 + 128;
+
+constexpr int NCOMPMAX = 128;       // unit capacity of the HL1 fleet tables
+constexpr int SEQ_NCOMPMAX = 256;   // component capacity of the sequential chronology (both tiles)
+struct SeqCase {
+    int32_t ncomp, hpy, mw, pad;    // mw: 32-bit mask words per hour (= the tile's OW: 4 or 8)
+    double mttf[SEQ_NCOMPMAX], mttr[SEQ_NCOMPMAX];
+};
+
+struct Hl1Case {
+    int32_t ngen, nhours;
+    uint32_t thr[NCOMPMAX];          // unit g down iff draw < thr[g]  (up iff rand() >= for_rate)
+    double cap[NCOMPMAX];
+};
+
 
 }  // namespace relmc

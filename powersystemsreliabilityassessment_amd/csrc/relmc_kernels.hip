@@ -14,15 +14,10 @@
 //    det = -(m*e + b^2) free of cancellation) whose symbolic structure, fill and task schedule
 //    are computed once per case on the host: the kernel only interprets a static list of
 //    passes (16 independent block tasks per pass and scenario) on a ~4 KB LDS workspace.
-#include <hip/hip_runtime.h>
-#include <stddef.h>
-#include <stdint.h>
-
-#include "relmc_dev.h"
+#include "relmc_devfn.h"
 
 namespace relmc {
 
-#define DEVFI __device__ __forceinline__
 
 // The first-dispatched wavefronts alternate between the lowest and the highest priority on this bit of the shader clock, sampled at the top of
 // every interior-point iteration (~29 500 clocks on both test systems).  Round 3 sweep (profiles/r3_pf/c37_*.log, c38_*.log; RTS-24 / RTS-96 against
@@ -31,153 +26,6 @@ namespace relmc {
 // On top of bit 12: high level 2 instead of 3, or a second evaluation before the Newton step: -0.2 % / +0.2 .. +1 % (c39_*.log), not taken.
 constexpr int kPrioBit = 12;
 constexpr int kMinWaves = 2;       // waves per SIMD the register allocator must allow (<= 256 VGPRs)
-
-template <int CTRL>
-DEVFI double dppd(double v) { return __builtin_amdgcn_update_dpp(v, v, CTRL, 0xf, 0xf, true); }
-template <int CTRL>
-DEVFI uint32_t dppu(uint32_t v) { return (uint32_t)__builtin_amdgcn_update_dpp((int)v, (int)v, CTRL, 0xf, 0xf, true); }
-
-// max / min as the single hardware instruction: __builtin_fmax would first canonicalise both inputs (two extra
-// v_max_f64 x, x, x per call); the instruction already returns the non-NaN operand, which is the fmax semantics
-DEVFI double vmax(double a, double b) { double r; __asm__("v_max_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-DEVFI double vmin(double a, double b) { double r; __asm__("v_min_f64 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b)); return r; }
-// all-reduce over the 16 lanes of a DPP row (row_ror 8,4,2,1); every lane gets bit-identical results
-DEVFI double row16_sum(double v) { v += dppd<0x128>(v); v += dppd<0x124>(v); v += dppd<0x122>(v); v += dppd<0x121>(v); return v; }
-DEVFI double row16_max(double v) { v = vmax(v, dppd<0x128>(v)); v = vmax(v, dppd<0x124>(v)); v = vmax(v, dppd<0x122>(v)); v = vmax(v, dppd<0x121>(v)); return v; }
-DEVFI double row16_min(double v) { v = vmin(v, dppd<0x128>(v)); v = vmin(v, dppd<0x124>(v)); v = vmin(v, dppd<0x122>(v)); v = vmin(v, dppd<0x121>(v)); return v; }
-DEVFI uint32_t row16_or(uint32_t v) { v |= dppu<0x128>(v); v |= dppu<0x124>(v); v |= dppu<0x122>(v); v |= dppu<0x121>(v); return v; }
-DEVFI uint32_t row16_add(uint32_t v) { v += dppu<0x128>(v); v += dppu<0x124>(v); v += dppu<0x122>(v); v += dppu<0x121>(v); return v; }
-
-// lane `l` of a wavefront as a wave-uniform (scalar) value; every lane of the wavefront must be active
-DEVFI double rdlane(double v, int l)
-{
-    union { double d; int i[2]; } u; u.d = v;
-    u.i[0] = __builtin_amdgcn_readlane(u.i[0], l); u.i[1] = __builtin_amdgcn_readlane(u.i[1], l);
-    return u.d;
-}
-// Scenario-row all-reduces.  RW = 16: the DPP row.  RW = 64: the DPP rows first, then the four row results are
-// combined in a fixed order from scalar registers (v_readlane), so the result is wave-uniform by construction.
-template <int RW> DEVFI double row_sum(double v)
-{
-    v = row16_sum(v);
-    if constexpr (RW == 64) v = (rdlane(v, 0) + rdlane(v, 16)) + (rdlane(v, 32) + rdlane(v, 48));
-    return v;
-}
-template <int RW> DEVFI double row_max(double v)
-{
-    v = row16_max(v);
-    if constexpr (RW == 64) v = vmax(vmax(rdlane(v, 0), rdlane(v, 16)), vmax(rdlane(v, 32), rdlane(v, 48)));
-    return v;
-}
-template <int RW> DEVFI double row_min(double v)
-{
-    v = row16_min(v);
-    if constexpr (RW == 64) v = vmin(vmin(rdlane(v, 0), rdlane(v, 16)), vmin(rdlane(v, 32), rdlane(v, 48)));
-    return v;
-}
-template <int RW> DEVFI uint32_t row_or(uint32_t v)
-{
-    v = row16_or(v);
-    if constexpr (RW == 64) v = (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) | __builtin_amdgcn_readlane((int)v, 16) | __builtin_amdgcn_readlane((int)v, 32) | __builtin_amdgcn_readlane((int)v, 48));
-    return v;
-}
-template <int RW> DEVFI uint32_t row_add(uint32_t v)
-{
-    v = row16_add(v);
-    if constexpr (RW == 64) v = (uint32_t)(__builtin_amdgcn_readlane((int)v, 0) + __builtin_amdgcn_readlane((int)v, 16) + __builtin_amdgcn_readlane((int)v, 32) + __builtin_amdgcn_readlane((int)v, 48));
-    return v;
-}
-template <int RW> DEVFI uint32_t row_min_u32(uint32_t v)
-{
-    v = min(v, dppu<0x128>(v)); v = min(v, dppu<0x124>(v)); v = min(v, dppu<0x122>(v)); v = min(v, dppu<0x121>(v));
-    if constexpr (RW == 64) v = min(min((uint32_t)__builtin_amdgcn_readlane((int)v, 0), (uint32_t)__builtin_amdgcn_readlane((int)v, 16)),
-                                    min((uint32_t)__builtin_amdgcn_readlane((int)v, 32), (uint32_t)__builtin_amdgcn_readlane((int)v, 48)));
-    return v;
-}
-// does any lane of this scenario row hold `p`?
-template <int RW> DEVFI bool row_any(bool p, int lane)
-{
-    const uint64_t b = __ballot(p);
-    if constexpr (RW == 64) return b != 0;
-    else return ((b >> (lane & 48)) & 0xffffull) != 0;
-}
-
-// 1/x to ~1 ulp (no IEEE division sequence): v_rcp_f64 is good to 4.4e-8 (measured on gfx950); with e = 1 - x r the exact reciprocal is
-// r (1 + e + e^2 + ...), so ONE cubic correction r (1 + e + e^2) leaves e^3 ~ 1e-22 and a single final rounding -- three FMAs where two
-// quadratic Newton steps take four (round 3: -0.6 % / -2.1 % kernel time on RTS-24 / RTS-96, results bit-identical to the two-step form)
-DEVFI double frcp(double x)
-{
-    const double r = __builtin_amdgcn_rcp(x);
-    const double e = __builtin_fma(-x, r, 1.0);
-    return __builtin_fma(r, __builtin_fma(e, e, e), r);
-}
-// 1/a and 1/b from ONE reciprocal: R = 1/(a b), 1/a = b R, 1/b = a R (a v_rcp_f64 is quarter rate and wants its correction, two
-// multiplications are cheaper; ~2 ulp instead of ~1), for the slack pair (z+, z-) and the multiplier pair (mu+, mu-) of a two-sided bound.
-// Round 3 measured it per call site (profiles/r3_rcp/pair_sites.log): at ALL eight sites -1.5 % / -0.8 % kernel time on RTS-24 / RTS-96, but the
-// state "G24 + G33 out" (0.3 % of all RTS-24 samples) moves from the oracle's 14 iterations to 15 -- at gamma ~ 1e-8 the Newton step of the
-// static-order factorisation carries enough noise along the LP's degenerate optimal face that one more rounding cuts a dual step (alpha_d 0.57
-// instead of 1, scripts/trace24.py), the extra iteration moves that state's nodal split by 6 MW on a bus and one bus' nodal sum of a sampled run
-// by 2 % against the oracle.  The injection evaluation (site 1) does that on its own, the injections' ratio-test multipliers (site 5) move
-// another fixture state, and combinations are not additive (0xDD and 0xD5 flip it again).  Shipped: the mask below -- line evaluation, the
-// lines' ratio tests, both updates -- under which every one of the 878 + 317 fixture states keeps its iteration count and 8 of 1e6 sampled
-// scenarios change theirs by one (-1.2 % kernel time).  On the 64-lane tile the same mask is 1.5 % SLOWER (the wide tile is bound by its chain, and
-// the pair form is one multiplication longer) and moves which RTS-96 states the primary order fails on, which the retry tests pin: it stays at the
-// round-2 arithmetic, bit for bit.  Mask 0 gives that on both tiles, 0xff all sites.
-constexpr int kRpairMask = 0xCD;     // 16-lane tile.  bit 0 / 1 evaluation lines / injections, 2 / 4 ratio-test slacks (lines / injections), 3 / 5 ratio-test multipliers, 6 / 7 update lines / injections
-constexpr int kInjNform = 1;         // 16-lane tile: injection evaluation with one reciprocal (of N = mu+ z- + mu- z+) instead of three
-constexpr int kInjNformWide = 0;     // 64-lane tile: the same, measured -0.75 % (with the pair mask 0xCD on top -0.85 %, profiles/r3_pf/c40_v96.log); not taken: with either, one of the
-                                    // 317 RTS-96 fixture states ends 6 iterations away from the C oracle (17 -> 23; the pin is +-1 on every state), tried and reverted
-constexpr int kRpairMaskWide = 0;    // 64-lane tile
-template <bool PAIR>
-DEVFI void frcp_pair(double a, double b, double& ra, double& rb)
-{
-    if constexpr (PAIR) {
-        const double R = frcp(a * b);
-        ra = b * R; rb = a * R;
-    } else {
-        ra = frcp(a); rb = frcp(b);
-    }
-}
-
-// 1/x to ~2e-15 relative (measured on gfx950: raw v_rcp_f64 4.4e-8, one Newton step 2.0e-15, two steps exact):
-// used where only a ratio-test bound is needed
-DEVFI double frcp1(double x)
-{
-    const double r = __builtin_amdgcn_rcp(x);
-    return __builtin_fma(r, __builtin_fma(-x, r, 1.0), r);
-}
-template <bool PAIR>
-DEVFI void frcp1_pair(double a, double b, double& ra, double& rb)
-{
-    if constexpr (PAIR) {
-        const double R = frcp1(a * b);
-        ra = b * R; rb = a * R;
-    } else {
-        ra = frcp1(a); rb = frcp1(b);
-    }
-}
-
-// Philox4x32-10 (Salmon et al. SC'11); counter (i_lo, i_hi, block, 0), key = seed
-DEVFI void philox4x32_10(uint32_t c0, uint32_t c1, uint32_t c2, uint32_t c3, uint32_t k0, uint32_t k1, uint32_t out[4])
-{
-#pragma unroll
-    for (int r = 0; r < 10; ++r) {
-        const uint32_t h0 = __umulhi(0xD2511F53u, c0), l0 = 0xD2511F53u * c0;
-        const uint32_t h1 = __umulhi(0xCD9E8D57u, c2), l1 = 0xCD9E8D57u * c2;
-        const uint32_t n0 = h1 ^ c1 ^ k0, n2 = h0 ^ c3 ^ k1;
-        c0 = n0; c1 = l1; c2 = n2; c3 = l0;
-        k0 += 0x9E3779B9u; k1 += 0xBB67AE85u;
-    }
-    out[0] = c0; out[1] = c1; out[2] = c2; out[3] = c3;
-}
-
-// outage mask of the scenario (bit k = component k failed), kept in LDS behind the workspace
-DEVFI bool outbit(const uint32_t* ob, int k) { return (ob[k >> 5] >> (k & 31)) & 1u; }
-
-struct __attribute__((aligned(16))) d2 { double x, y; };
-DEVFI d2 ld2(const double* p) { return *reinterpret_cast<const d2*>(p); }
-DEVFI void st2(double* p, double x, double y) { d2 v; v.x = x; v.y = y; *reinterpret_cast<d2*>(p) = v; }
-
 #define DINF __builtin_inf()
 // compiler-only fence: stops LICM from parking loop-invariant LDS table reads in VGPRs for the whole
 // kernel (registers are the scarce resource here, LDS reads are cheap)
@@ -1449,16 +1297,6 @@ __global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(con
     PT_FLUSH
 }
 
-// device image of relmc_acc (include/relmc.h): 6 + 256 int64, then 2 + 128 doubles
-struct DevAcc {
-    long long n, n_fail, n_singular, n_infeasible, n_nonconverged, sum_iters;
-    long long comp_fail[256];
-    double sum_dns, sum_dns2;
-    double sum_nodal[128];
-};
-
-constexpr int FIN_ITEMS = 8 + 256 + 128;
-
 // One workgroup (one wavefront) per output element; the scenario rows are summed lane-strided and
 // combined by a fixed butterfly, so the accumulators are bit-reproducible for a launch geometry.
 template <class TL>
@@ -1527,491 +1365,6 @@ __global__ void __launch_bounds__(256) relmc_sampling_kernel(const DevCaseT<TL>*
             if (k < ncomp) eqstatus[i * ncomp + k] = w[e] < C->thr[k] ? 1 : 0;
         }
     }
-}
-
-// ---- sequential track (Montecarlo_seq/): chronology sampling, contingency-hour compaction, annual indices ----
-// ---- distinct-state path (nsqMain.m:220-245): masks of a sampled range, sorted and run-length encoded on the device ----
-// one thread per scenario: the same draws as relmc_sampling_kernel / MODE 0, packed as OW mask words
-template <class TL>
-__global__ void __launch_bounds__(256) relmc_memo_keys_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index,
-                                                              int64_t n, uint32_t* __restrict__ keys)
-{
-    constexpr int OW = TL::OW;
-    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t gi = first_index + (uint64_t)i;
-        uint32_t w[OW];
-#pragma unroll
-        for (int q = 0; q < OW; ++q) w[q] = 0;
-        for (int blk = 0; blk < nblk; ++blk) {
-            uint32_t r[4];
-            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            uint32_t nib = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
-#pragma unroll
-            for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
-        }
-#pragma unroll
-        for (int q = 0; q < OW; ++q) keys[(size_t)i * OW + q] = w[q];
-    }
-}
-
-// 64-bit chunk c of the masks in the current order (LSD radix passes, least significant chunk first)
-__global__ void __launch_bounds__(256) relmc_memo_chunk_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int ow, int c,
-                                                               int64_t n, unsigned long long* __restrict__ out)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        const uint32_t* kp = keys + (size_t)perm[j] * ow + 2 * c;
-        out[j] = (unsigned long long)kp[0] | ((unsigned long long)kp[1] << 32);
-    }
-}
-
-__global__ void __launch_bounds__(256) relmc_memo_iota_kernel(int64_t n, uint32_t* __restrict__ perm)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) perm[j] = (uint32_t)j;
-}
-
-// head[j] = 1 when sorted position j starts a new distinct mask
-__global__ void __launch_bounds__(256) relmc_memo_heads_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm, int ow, int64_t n,
-                                                               uint32_t* __restrict__ head)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        uint32_t h = 1;
-        if (j > 0) {
-            const uint32_t* ka = keys + (size_t)perm[j] * ow; const uint32_t* kb = keys + (size_t)perm[j - 1] * ow;
-            h = 0;
-            for (int q = 0; q < ow; ++q) h |= (ka[q] != kb[q]) ? 1u : 0u;
-        }
-        head[j] = h;
-    }
-}
-
-// start[u] = first sorted position of distinct mask u; start[n_distinct] = n; *n_distinct_out = number of distinct masks
-__global__ void __launch_bounds__(256) relmc_memo_starts_kernel(const uint32_t* __restrict__ head, const uint32_t* __restrict__ uid, int64_t n,
-                                                                uint32_t* __restrict__ start, uint32_t* __restrict__ n_distinct_out)
-{
-    for (int64_t j = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; j < n; j += (int64_t)gridDim.x * blockDim.x) {
-        if (head[j]) start[uid[j]] = (uint32_t)j;
-        if (j == n - 1) { const uint32_t nu = uid[j] + head[j]; start[nu] = (uint32_t)n; *n_distinct_out = nu; }
-    }
-}
-
-// ---- persistent state database (nsqMain.m:91-99, 220-278): one row per distinct state ever sampled -------------------
-// Rows live in HBM as parallel arrays keys[cap][ow] (outage mask words), count[cap], dns[cap], meta[cap] (status |
-// relaxed << 2 | iterations << 8), nodal[cap][nb]; an open-addressing table of row ids (linear probing, full-key
-// compares) finds a state.  Rows are appended in the order of first appearance in the global sample stream, which makes
-// the database (and every fp64 sum over it) independent of the batch size.
-constexpr uint32_t DB_EMPTY = 0xffffffffu;
-DEVFI uint64_t db_hash(const uint32_t* k, int ow)
-{
-    uint64_t h = 0x9E3779B97F4A7C15ull;
-    for (int q = 0; q < ow; ++q) { h = (h ^ k[q]) * 0xff51afd7ed558ccdull; h ^= h >> 29; }
-    return h;
-}
-
-// nsqMain.m:232-245 for the distinct states of one batch (unique within the batch, so no two threads touch the same row):
-// known state -> its count grows by the multiplicity; unknown -> flagged with the index of its first sample (the sort key
-// that orders the new rows by first appearance); states[u] = keys[perm[start[u]]], multiplicity start[u+1] - start[u]
-__global__ void __launch_bounds__(256) relmc_db_lookup_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
-                                                              const uint32_t* __restrict__ start, uint32_t nu, int ow,
-                                                              const uint32_t* __restrict__ db_keys, unsigned long long* __restrict__ db_count,
-                                                              const uint32_t* __restrict__ table, uint64_t tmask,
-                                                              uint32_t* __restrict__ first_idx, uint32_t* __restrict__ uid, uint32_t* __restrict__ n_new)
-{
-    for (uint32_t u = blockIdx.x * blockDim.x + threadIdx.x; u < nu; u += gridDim.x * blockDim.x) {
-        const uint32_t s0 = start[u], first = perm[s0];          // stable sort: the run's first entry is the earliest sample
-        const uint32_t* k = keys + (size_t)first * ow;
-        uint64_t h = db_hash(k, ow) & tmask;
-        uint32_t found = DB_EMPTY;
-        for (;;) {
-            const uint32_t r = table[h];
-            if (r == DB_EMPTY) break;
-            const uint32_t* dk = db_keys + (size_t)r * ow;
-            bool eq = true;
-            for (int q = 0; q < ow; ++q) eq = eq && dk[q] == k[q];
-            if (eq) { found = r; break; }
-            h = (h + 1) & tmask;
-        }
-        uid[u] = u;
-        if (found != DB_EMPTY) { db_count[found] += (unsigned long long)(start[u + 1] - s0); first_idx[u] = DB_EMPTY; }
-        else { first_idx[u] = first; atomicAdd(n_new, 1u); }
-    }
-}
-
-// nsqMain.m:269-278, the state and count columns of the new rows: row db_n + k = k-th new state in order of first appearance
-__global__ void __launch_bounds__(256) relmc_db_insert_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ perm,
-                                                              const uint32_t* __restrict__ start, const uint32_t* __restrict__ sorted_u, uint32_t n_new,
-                                                              int ow, uint64_t db_n, uint32_t* __restrict__ db_keys,
-                                                              unsigned long long* __restrict__ db_count, uint32_t* __restrict__ table, uint64_t tmask)
-{
-    for (uint32_t k = blockIdx.x * blockDim.x + threadIdx.x; k < n_new; k += gridDim.x * blockDim.x) {
-        const uint32_t u = sorted_u[k], s0 = start[u];
-        const uint32_t* src = keys + (size_t)perm[s0] * ow;
-        const uint64_t row = db_n + k;
-        uint32_t* dst = db_keys + row * ow;
-        for (int q = 0; q < ow; ++q) dst[q] = src[q];
-        db_count[row] = (unsigned long long)(start[u + 1] - s0);
-        uint64_t h = db_hash(src, ow) & tmask;
-        while (atomicCAS(&table[h], DB_EMPTY, (uint32_t)row) != DB_EMPTY) h = (h + 1) & tmask;   // keys are distinct: claim the first free slot
-    }
-}
-
-// nsqMain.m:232-245 per SAMPLE, before any sorting (round 2b): every sample of the batch computes its mask and probes the table.
-// Hit (the large majority once the database is warm: >= 96 % on RTS-24): the row's count grows — pre-aggregated per block in a
-// small LDS hash so that the all-up state and the single-outage states do not serialise on one L2 atomic.  Miss: the sample's
-// index and mask are appended to a miss list; only that list goes through the dedupe sort.
-template <class TL>
-__global__ void __launch_bounds__(256) relmc_db_probe_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index, int64_t n,
-                                                             const uint32_t* __restrict__ db_keys, unsigned long long* __restrict__ db_count,
-                                                             const uint32_t* __restrict__ table, uint64_t tmask,
-                                                             uint32_t* __restrict__ miss_idx, uint32_t* __restrict__ miss_keys, uint32_t* __restrict__ n_miss)
-{
-    constexpr int OW = TL::OW;
-    constexpr int LH = 512;
-    __shared__ uint32_t lrow[LH];
-    __shared__ uint32_t lcnt[LH];
-    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2, tid = threadIdx.x;
-    for (int k = tid; k < LH; k += 256) { lrow[k] = DB_EMPTY; lcnt[k] = 0; }
-    __syncthreads();
-    constexpr int SUB = 4;                                   // samples per thread between two flushes of the block's table
-    for (int64_t base = (int64_t)blockIdx.x * 256 * SUB; base < n; base += (int64_t)gridDim.x * 256 * SUB) {
-      for (int sub = 0; sub < SUB; ++sub) {
-        const int64_t i = base + sub * 256 + tid;
-        if (i < n) {
-            const uint64_t gi = first_index + (uint64_t)i;
-            uint32_t w[OW];
-#pragma unroll
-            for (int q = 0; q < OW; ++q) w[q] = 0;
-            for (int blk = 0; blk < nblk; ++blk) {
-                uint32_t r[4];
-                philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-                uint32_t nib = 0;
-#pragma unroll
-                for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
-#pragma unroll
-                for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
-            }
-            uint64_t h = db_hash(w, OW) & tmask;
-            uint32_t found = DB_EMPTY;
-            for (;;) {
-                const uint32_t r = table[h];
-                if (r == DB_EMPTY) break;
-                const uint32_t* dk = db_keys + (size_t)r * OW;
-                bool eq = true;
-#pragma unroll
-                for (int q = 0; q < OW; ++q) eq = eq && dk[q] == w[q];
-                if (eq) { found = r; break; }
-                h = (h + 1) & tmask;
-            }
-            if (found != DB_EMPTY) {
-                uint32_t sl = (found * 2654435761u) >> 23;                 // 9 bits
-                for (int tries = 0; ; ++tries) {
-                    const uint32_t old = atomicCAS(&lrow[sl], DB_EMPTY, found);
-                    if (old == DB_EMPTY || old == found) { atomicAdd(&lcnt[sl], 1u); break; }
-                    if (tries == LH) { atomicAdd(&db_count[found], 1ull); break; }      // block table full: straight to memory
-                    sl = (sl + 1) & (LH - 1);
-                }
-            } else {
-                const uint32_t pos = atomicAdd(n_miss, 1u);
-                miss_idx[pos] = (uint32_t)i;
-#pragma unroll
-                for (int q = 0; q < OW; ++q) miss_keys[(size_t)pos * OW + q] = w[q];
-            }
-        }
-      }
-        __syncthreads();
-        for (int k = tid; k < LH; k += 256) {
-            if (lrow[k] != DB_EMPTY) { atomicAdd(&db_count[lrow[k]], (unsigned long long)lcnt[k]); lrow[k] = DB_EMPTY; lcnt[k] = 0; }
-        }
-        __syncthreads();
-    }
-}
-
-// dns of every sample of a range whose states are all in the database already (the range has just been through
-// relmc_nsq_db_batch): out[i] = dns of the row holding sample i's state, NaN if there is none.  Feeds the per-checkpoint
-// indices of small batches (relmc_nsq_run), which need the order of the samples the count-weighted rows no longer have.
-template <class TL>
-__global__ void __launch_bounds__(256) relmc_db_sample_dns_kernel(const DevCaseT<TL>* __restrict__ C, uint64_t seed, uint64_t first_index, int64_t n,
-                                                                  const uint32_t* __restrict__ db_keys, const double* __restrict__ db_dns,
-                                                                  const uint32_t* __restrict__ table, uint64_t tmask, double* __restrict__ out)
-{
-    constexpr int OW = TL::OW;
-    const int ncomp = C->ncomp, nblk = (ncomp + 3) >> 2;
-    for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < n; i += (int64_t)gridDim.x * 256) {
-        const uint64_t gi = first_index + (uint64_t)i;
-        uint32_t w[OW];
-#pragma unroll
-        for (int q = 0; q < OW; ++q) w[q] = 0;
-        for (int blk = 0; blk < nblk; ++blk) {
-            uint32_t r[4];
-            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), r);
-            uint32_t nib = 0;
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int k = blk * 4 + e; if (k < ncomp && r[e] < C->thr[k]) nib |= 1u << e; }
-#pragma unroll
-            for (int q = 0; q < OW; ++q) if (q == (blk >> 3)) w[q] |= nib << ((blk & 7) * 4);
-        }
-        uint64_t h = db_hash(w, OW) & tmask;
-        double v = __builtin_nan("");
-        for (;;) {
-            const uint32_t r = table[h];
-            if (r == DB_EMPTY) break;
-            const uint32_t* dk = db_keys + (size_t)r * OW;
-            bool eq = true;
-#pragma unroll
-            for (int q = 0; q < OW; ++q) eq = eq && dk[q] == w[q];
-            if (eq) { v = db_dns[r]; break; }
-            h = (h + 1) & tmask;
-        }
-        out[i] = v;
-    }
-}
-
-// the misses in ascending sample order: keys[r] = miss_keys[pos_sorted[r]] (the dedupe's stable sort then keeps, within equal masks,
-// the earliest sample first)
-__global__ void __launch_bounds__(256) relmc_db_gather_keys_kernel(const uint32_t* __restrict__ miss_keys, const uint32_t* __restrict__ pos_sorted, int ow,
-                                                                   uint32_t n, uint32_t* __restrict__ keys)
-{
-    for (uint32_t r = blockIdx.x * blockDim.x + threadIdx.x; r < n; r += gridDim.x * blockDim.x) {
-        const uint32_t* src = miss_keys + (size_t)pos_sorted[r] * ow;
-        for (int q = 0; q < ow; ++q) keys[(size_t)r * ow + q] = src[q];
-    }
-}
-
-// table of row ids rebuilt after the database has grown
-__global__ void __launch_bounds__(256) relmc_db_rehash_kernel(const uint32_t* __restrict__ db_keys, uint64_t rows, int ow,
-                                                              uint32_t* __restrict__ table, uint64_t tmask)
-{
-    for (uint64_t r = (uint64_t)blockIdx.x * blockDim.x + threadIdx.x; r < rows; r += (uint64_t)gridDim.x * blockDim.x) {
-        uint64_t h = db_hash(db_keys + r * ow, ow) & tmask;
-        while (atomicCAS(&table[h], DB_EMPTY, (uint32_t)r) != DB_EMPTY) h = (h + 1) & tmask;
-    }
-}
-
-// nsqMain.m:282-301, 348-349, 366-376 over the whole database: the count-weighted sums of the rows (stage 1: one partial
-// accumulator image per block of `chunk` consecutive rows; fp64 sums in a fixed order, integer sums by LDS atomics)
-__global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, int ncomp, double fail_threshold, const uint32_t* __restrict__ keys,
-                                                              const unsigned long long* __restrict__ count, const double* __restrict__ dns,
-                                                              const int32_t* __restrict__ meta, const double* __restrict__ nodal,
-                                                              uint64_t rows, uint64_t chunk, DevAcc* __restrict__ partial)
-{
-    __shared__ unsigned long long si[6 + 256];
-    __shared__ double sd[2][256];
-    __shared__ double sn[8][128];
-    const int t = threadIdx.x;
-    for (int k = t; k < 6 + 256; k += 256) si[k] = 0ull;
-    __syncthreads();
-    const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < rows ? lo + chunk : rows;
-    unsigned long long c_n = 0, c_fail = 0, c_sing = 0, c_inf = 0, c_nc = 0, c_it = 0;
-    double s1 = 0.0, s2 = 0.0;
-    for (uint64_t r = lo + t; r < hi; r += 256) {
-        const unsigned long long c = count[r];
-        const double d = dns[r];
-        const uint32_t m = (uint32_t)meta[r];
-        const uint32_t st = m & 3u;
-        c_n += c;
-        c_it += c * (unsigned long long)(m >> 8);
-        if (st == 3u) c_sing += c;
-        if (st == 1u || st == 2u) c_nc += c;
-        if (m & 4u) c_inf += c;
-        if (d != 0.0) { const double cd = (double)c; s1 = __builtin_fma(cd, d, s1); s2 = __builtin_fma(cd * d, d, s2); }
-        if (d > fail_threshold) {                        // nsqMain.m:270
-            c_fail += c;
-            for (int q = 0; q < ow; ++q) {
-                uint32_t w = keys[r * ow + q];
-                while (w) { const int b = __ffs((int)w) - 1; w &= w - 1; atomicAdd(&si[6 + 32 * q + b], c); }
-            }
-        }
-    }
-    atomicAdd(&si[0], c_n); atomicAdd(&si[1], c_fail); atomicAdd(&si[2], c_sing); atomicAdd(&si[3], c_inf); atomicAdd(&si[4], c_nc); atomicAdd(&si[5], c_it);
-    sd[0][t] = s1; sd[1][t] = s2;
-    // nodal columns: thread (g, bl) sums bus columns bl, bl + 32, ... over the rows lo + g, lo + g + 8, ...
-    const int g = t >> 5, bl = t & 31;
-    double a0 = 0.0, a1 = 0.0, a2 = 0.0, a3 = 0.0;
-    for (uint64_t r = lo + g; r < hi; r += 8) {
-        if (dns[r] > 0.0) {                              // mc_simulation.m:65: nodal shed only where load was curtailed
-            const double cd = (double)count[r];
-            const double* nr = nodal + r * nb;
-            if (bl < nb) a0 = __builtin_fma(cd, nr[bl], a0);
-            if (bl + 32 < nb) a1 = __builtin_fma(cd, nr[bl + 32], a1);
-            if (bl + 64 < nb) a2 = __builtin_fma(cd, nr[bl + 64], a2);
-            if (bl + 96 < nb) a3 = __builtin_fma(cd, nr[bl + 96], a3);
-        }
-    }
-    sn[g][bl] = a0; sn[g][bl + 32] = a1; sn[g][bl + 64] = a2; sn[g][bl + 96] = a3;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (t < off) { sd[0][t] += sd[0][t + off]; sd[1][t] += sd[1][t + off]; }
-        __syncthreads();
-    }
-    DevAcc& out = partial[blockIdx.x];
-    long long* oi = reinterpret_cast<long long*>(&out);
-    for (int k = t; k < 6 + 256; k += 256) oi[k] = (long long)si[k];
-    if (t == 0) { out.sum_dns = sd[0][0]; out.sum_dns2 = sd[1][0]; }
-    if (t < 128) out.sum_nodal[t] = ((sn[0][t] + sn[1][t]) + (sn[2][t] + sn[3][t])) + ((sn[4][t] + sn[5][t]) + (sn[6][t] + sn[7][t]));
-    (void)ncomp;
-}
-
-// stage 2: one wavefront per accumulator word sums the block partials lane-strided and combines them by a fixed butterfly
-__global__ void __launch_bounds__(64) relmc_db_final_kernel(const DevAcc* __restrict__ partial, int nblocks, DevAcc* __restrict__ out)
-{
-    constexpr int NI = 6 + 256;
-    const int item = blockIdx.x, lane = threadIdx.x;
-    long long si = 0; double sd = 0.0;
-    for (int b = lane; b < nblocks; b += 64) {
-        if (item < NI) si += reinterpret_cast<const long long*>(&partial[b])[item];
-        else sd += (&partial[b].sum_dns)[item - NI];
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { si += __shfl_xor(si, off); sd += __shfl_xor(sd, off); }
-    if (lane == 0) {
-        if (item < NI) reinterpret_cast<long long*>(out)[item] = si;
-        else (&out->sum_dns)[item - NI] = sd;
-    }
-}
-
-constexpr int NCOMPMAX = 128;       // unit capacity of the HL1 fleet tables
-constexpr int SEQ_NCOMPMAX = 256;   // component capacity of the sequential chronology (both tiles)
-struct SeqCase {
-    int32_t ncomp, hpy, mw, pad;    // mw: 32-bit mask words per hour (= the tile's OW: 4 or 8)
-    double mttf[SEQ_NCOMPMAX], mttr[SEQ_NCOMPMAX];
-};
-
-// seq_mcsampling.m:35-76, one thread per (year, component): alternate TTF = round(-MTTF ln U) and
-// TTR = ceil(-MTTR ln U), every year starts all-up (seqMain.m:91 calls it with num_years = 1).  U of event e of
-// component k in global year y = (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key=seed)[e & 3] + 0.5) / 2^32.
-// Down hours are OR-ed into masks[year][hour][mw x u32] (bit k), which must be zero on entry.
-__global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* __restrict__ Q, uint64_t seed, uint64_t first_year,
-                                                                 int32_t n_years, uint32_t* __restrict__ masks)
-{
-    const int ncomp = Q->ncomp, hpy = Q->hpy, mw = Q->mw;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)n_years * ncomp) return;
-    const int y = (int)(t / ncomp), k = (int)(t - (int64_t)y * ncomp);
-    const uint64_t gy = first_year + (uint64_t)y;
-    const double mttf = Q->mttf[k], mttr = Q->mttr[k];
-    long long current = 0;
-    bool up = true;
-    uint32_t w[4];
-    for (int ev = 0; current < hpy; ++ev) {
-        if ((ev & 3) == 0)
-            philox4x32_10((uint32_t)gy, (uint32_t)(gy >> 32), (uint32_t)k | 0x80000000u, (uint32_t)(ev >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-        const double u = ((double)w[ev & 3] + 0.5) * 2.3283064365386963e-10;   // (0, 1)
-        if (up) {
-            current += (long long)__builtin_floor(-mttf * log(u) + 0.5);        // round(), seq_mcsampling.m:53
-        } else {
-            const long long dur = (long long)__builtin_ceil(-mttr * log(u));    // ceil(), >= 1 h, seq_mcsampling.m:60
-            long long end = current + dur - 1;
-            if (end > hpy - 1) end = hpy - 1;
-            for (long long h = current; h <= end; ++h)
-                atomicOr(&masks[((size_t)y * hpy + (size_t)h) * mw + (k >> 5)], 1u << (k & 31));
-            current += dur;
-        }
-        up = !up;
-    }
-}
-
-// masks -> uint8 states [years][hours][ncomp] (the materialised seq_mcsampling output)
-__global__ void __launch_bounds__(256) relmc_seq_expand_kernel(const uint32_t* __restrict__ masks, int64_t nhours_total, int ncomp, int mw,
-                                                               uint8_t* __restrict__ states)
-{
-    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < nhours_total * ncomp; t += (int64_t)gridDim.x * blockDim.x) {
-        const int64_t h = t / ncomp; const int k = (int)(t - h * ncomp);
-        states[t] = (masks[h * mw + (k >> 5)] >> (k & 31)) & 1u;
-    }
-}
-
-// seqMain.m:97-100: hours with at least one component down, kept in ascending order (one workgroup per year)
-__global__ void __launch_bounds__(256) relmc_seq_compact_kernel(const uint32_t* __restrict__ masks, int hpy, int mw, uint16_t* __restrict__ hours,
-                                                                uint32_t* __restrict__ counts)
-{
-    __shared__ uint32_t wsum[4];
-    __shared__ uint32_t base;
-    const int y = blockIdx.x, tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
-    if (tid == 0) base = 0;
-    __syncthreads();
-    for (int h0 = 0; h0 < hpy; h0 += 256) {
-        const int h = h0 + tid;
-        bool f = false;
-        if (h < hpy) { const uint32_t* m = masks + ((size_t)y * hpy + h) * mw; uint32_t o = 0; for (int q = 0; q < mw; ++q) o |= m[q]; f = o != 0; }
-        const uint64_t b = __ballot(f);
-        const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
-        if (lane == 0) wsum[wv] = (uint32_t)__popcll(b);
-        __syncthreads();
-        uint32_t off = base;
-        for (int q = 0; q < wv; ++q) off += wsum[q];
-        if (f) hours[(size_t)y * hpy + off + before] = (uint16_t)h;
-        __syncthreads();
-        if (tid == 0) base += wsum[0] + wsum[1] + wsum[2] + wsum[3];
-        __syncthreads();
-    }
-    if (tid == 0) counts[y] = base;
-}
-
-// seqMain.m:136-176 + calnlc.m:22-32: annual loss hours (dlc), loss events (nlc = rising edges of the loss flag,
-// hour 1 counts) and energy not supplied; one workgroup per year, fixed summation order.
-__global__ void __launch_bounds__(256) relmc_seq_annual_kernel(const double* __restrict__ curt, int hpy, double threshold,
-                                                               double* __restrict__ year_out /* [years][3] = ens, dlc, nlc */)
-{
-    __shared__ double red[3][256];
-    const int y = blockIdx.x, tid = threadIdx.x;
-    const double* c = curt + (size_t)y * hpy;
-    double ens = 0.0, dlc = 0.0, nlc = 0.0;
-    for (int h = tid; h < hpy; h += 256) {
-        const double v = c[h];
-        const bool f = v > threshold;
-        ens += v;
-        if (f) { dlc += 1.0; if (h == 0 || !(c[h - 1] > threshold)) nlc += 1.0; }
-    }
-    red[0][tid] = ens; red[1][tid] = dlc; red[2][tid] = nlc;
-    __syncthreads();
-    for (int off = 128; off > 0; off >>= 1) {
-        if (tid < off) { red[0][tid] += red[0][tid + off]; red[1][tid] += red[1][tid + off]; red[2][tid] += red[2][tid + off]; }
-        __syncthreads();
-    }
-    if (tid < 3) year_out[(size_t)y * 3 + tid] = red[tid][0];
-}
-
-// ---- HL1 copper sheet (PowerSystemAdequacy.jl:169-208): one thread per iteration ------------------
-struct Hl1Case {
-    int32_t ngen, nhours;
-    uint32_t thr[NCOMPMAX];          // unit g down iff draw < thr[g]  (up iff rand() >= for_rate)
-    double cap[NCOMPMAX];
-};
-
-// sorted[] = hourly loads ascending, suffix[k] = sum(sorted[k:]); loss hours = #{load > cap}, deficit by suffix sums
-__global__ void __launch_bounds__(256) relmc_hl1_kernel(const Hl1Case* __restrict__ H, const double* __restrict__ sorted,
-                                                        const double* __restrict__ suffix, uint64_t seed, uint64_t first_index,
-                                                        int64_t n, double* __restrict__ iter_lole, double* __restrict__ iter_eue,
-                                                        double* __restrict__ partial)
-{
-    __shared__ double red[4][4];
-    const int ngen = H->ngen, nh = H->nhours;
-    double s_l = 0.0, s_e = 0.0, s_l2 = 0.0, s_e2 = 0.0;
-    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < n; i += (int64_t)gridDim.x * blockDim.x) {
-        const uint64_t gi = first_index + (uint64_t)i;
-        double cap = 0.0;
-        for (int blk = 0; blk * 4 < ngen; ++blk) {
-            uint32_t w[4];
-            philox4x32_10((uint32_t)gi, (uint32_t)(gi >> 32), (uint32_t)blk, 0u, (uint32_t)seed, (uint32_t)(seed >> 32), w);
-#pragma unroll
-            for (int e = 0; e < 4; ++e) { const int g = blk * 4 + e; if (g < ngen && !(w[e] < H->thr[g])) cap += H->cap[g]; }
-        }
-        int lo = 0, hi = nh;                          // first index with sorted[idx] > cap  (cap < load, :192)
-        while (lo < hi) { const int mid = (lo + hi) >> 1; if (sorted[mid] > cap) hi = mid; else lo = mid + 1; }
-        const double hours = (double)(nh - lo);
-        const double eue = lo < nh ? suffix[lo] - cap * hours : 0.0;
-        if (iter_lole) iter_lole[i] = hours;
-        if (iter_eue) iter_eue[i] = eue;
-        s_l += hours; s_e += eue; s_l2 = __builtin_fma(hours, hours, s_l2); s_e2 = __builtin_fma(eue, eue, s_e2);
-    }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) { s_l += __shfl_xor(s_l, off); s_e += __shfl_xor(s_e, off); s_l2 += __shfl_xor(s_l2, off); s_e2 += __shfl_xor(s_e2, off); }
-    const int wv = threadIdx.x >> 6;
-    if ((threadIdx.x & 63) == 0) { red[wv][0] = s_l; red[wv][1] = s_e; red[wv][2] = s_l2; red[wv][3] = s_e2; }
-    __syncthreads();
-    if (threadIdx.x < 4) partial[(size_t)blockIdx.x * 4 + threadIdx.x] = red[0][threadIdx.x] + red[1][threadIdx.x] + red[2][threadIdx.x] + red[3][threadIdx.x];
 }
 
 // probe used by the unit tests: row broadcast / row all-reduce semantics the solver relies on

@@ -1,0 +1,245 @@
+// relmc_seq.hip — the sequential (chronological) HL2 track of /root/reference/Montecarlo_seq/ (seq_mcsampling.m, seq_mcsimulation.m, calnlc.m,
+// seqMain.m:85-249) and the HL1 copper-sheet model of GeneratingAdequacy/PowerSystemAdequacy.jl:169-208.
+#include <algorithm>
+#include <chrono>
+#include <cmath>
+#include <cstring>
+
+#include "relmc_ctx.h"
+#include "relmc_seq_kernels.h"
+
+namespace relmc_host {
+
+void seq_free(relmc_ctx* ctx)
+{
+    for (void* q : {(void*)ctx->sq_dm, (void*)ctx->sq_hours, (void*)ctx->sq_curt, (void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year, (void*)ctx->dseq,
+                    (void*)ctx->dlf, (void*)ctx->dhl1, (void*)ctx->dsorted, (void*)ctx->dsuffix}) if (q) (void)hipFree(q);
+    ctx->sq_dm = nullptr; ctx->sq_hours = nullptr; ctx->sq_curt = nullptr; ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr;
+    ctx->sq_dm_words = 0; ctx->sq_nh = 0; ctx->sq_years = 0;
+    ctx->dseq = nullptr; ctx->dlf = nullptr; ctx->dhl1 = nullptr; ctx->dsorted = ctx->dsuffix = nullptr; ctx->has_seq = false; ctx->has_hl1 = false;
+}
+
+namespace {
+// chronology of years [first_year, first_year + n_years) into freshly zeroed device masks
+// *dmasks_out == nullptr on entry: a buffer is allocated for the caller (who frees it); otherwise the masks go into the caller's buffer
+int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, uint32_t** dmasks_out)
+{
+    const size_t words = (size_t)n_years * ctx->hseq.hpy * ctx->hseq.mw;
+    const bool own = *dmasks_out == nullptr;
+    uint32_t* dm = *dmasks_out;
+    if (own) HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
+    if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
+    const int64_t nthr = (int64_t)n_years * ctx->hseq.ncomp;
+    hipLaunchKernelGGL(relmc_seq_sampling_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dseq, seed, first_year, n_years, dm);
+    if (hipGetLastError() != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: sampling launch failed"); }
+    *dmasks_out = dm;
+    return RELMC_OK;
+}
+}  // namespace
+
+}  // namespace relmc_host
+
+using namespace relmc_host;
+
+extern "C" {
+
+// ---- sequential HL2: Montecarlo_seq/ ---------------------------------------------------------------------
+int32_t relmc_seq_load(relmc_ctx* ctx, const double* mttf, const double* mttr, int32_t hpy, const double* load_factors)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_load: no case loaded");
+    if (!mttf || !mttr || !load_factors || hpy < 1 || hpy > 65535) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: bad arguments");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    SeqCase& q = ctx->hseq;
+    std::memset(&q, 0, sizeof(q));
+    if (ctx->ncomp > SEQ_NCOMPMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_seq_load: more than 256 components");
+    q.ncomp = ctx->ncomp; q.hpy = hpy; q.mw = ctx->tile == 0 ? Tile24::OW : Tile96::OW;
+    for (int k = 0; k < q.ncomp; ++k) {
+        if (!(mttf[k] > 0) || !(mttr[k] > 0)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_load: MTTF / MTTR must be positive");
+        q.mttf[k] = mttf[k]; q.mttr[k] = mttr[k];
+    }
+    if (!ctx->dseq) HIP_TRY(ctx, hipMalloc(&ctx->dseq, sizeof(SeqCase)));
+    if (ctx->dlf) (void)hipFree(ctx->dlf);
+    ctx->dlf = nullptr;
+    HIP_TRY(ctx, hipMalloc(&ctx->dlf, sizeof(double) * hpy));
+    ctx->hlf.assign(load_factors, load_factors + hpy);
+    HIP_TRY(ctx, hipMemcpy(ctx->dseq, &q, sizeof(q), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dlf, load_factors, sizeof(double) * hpy, hipMemcpyHostToDevice));
+    ctx->has_seq = true;
+    return RELMC_OK;
+}
+
+int32_t relmc_seq_mcsampling(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t num_years, uint8_t* state_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_mcsampling: relmc_seq_load has not been called");
+    if (num_years < 0 || (num_years > 0 && !state_host)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_mcsampling: bad arguments");
+    if (num_years == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    uint32_t* dm = nullptr;
+    int rc = seq_sample(ctx, seed, first_year, num_years, &dm);
+    if (rc) return rc;
+    const int64_t nh = (int64_t)num_years * ctx->hseq.hpy;
+    const size_t bytes = (size_t)nh * ctx->hseq.ncomp;
+    uint8_t* dst = nullptr;
+    if (hipMalloc(&dst, bytes) != hipSuccess) { (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: allocation failed"); }
+    hipLaunchKernelGGL(relmc_seq_expand_kernel, dim3(ctx->num_cu * 8), dim3(256), 0, ctx->stream, dm, nh, ctx->hseq.ncomp, ctx->hseq.mw, dst);
+    if (hipGetLastError() != hipSuccess || hipStreamSynchronize(ctx->stream) != hipSuccess ||
+        hipMemcpy(state_host, dst, bytes, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_seq_mcsampling: kernel / copy failed");
+    (void)hipFree(dm); (void)hipFree(dst);
+    return rc;
+}
+
+int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const double* load_scale_host, int64_t n, const relmc_solver_opts* opts,
+                               double* dns_host, double* nodal_host, int32_t* status_host, int32_t* iters_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_case) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_mcsimulation: no case loaded");
+    if (n < 0 || (n > 0 && (!states_host || !dns_host || !load_scale_host))) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_mcsimulation: bad arguments");
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    return pipe_run(ctx, states_host, load_scale_host, n, o, 0.01 /* CURTAIL_THRESHOLD, seqMain.m:41 */, dns_host, nodal_host, status_host, iters_host);
+}
+
+int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t n_years, const relmc_solver_opts* opts,
+                        double curtail_threshold, relmc_seq_year* years_out, relmc_acc* acc_out)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_years: relmc_seq_load has not been called");
+    if (n_years < 0 || !acc_out || (n_years > 0 && !years_out)) return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_years: bad arguments");
+    relmc_acc_zero(acc_out);
+    if (n_years == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    relmc_solver_opts o;
+    if (opts) o = *opts; else relmc_solver_opts_default(&o);
+    const int hpy = ctx->hseq.hpy;
+    // the device buffers of a step live in the context and only ever grow
+    const size_t nh = (size_t)n_years * hpy, words = nh * (size_t)ctx->hseq.mw;
+    bool alloc_ok = true;
+    if (ctx->sq_dm_words < words) { if (ctx->sq_dm) (void)hipFree(ctx->sq_dm); ctx->sq_dm = nullptr; ctx->sq_dm_words = 0;
+                                    alloc_ok = hipMalloc(&ctx->sq_dm, words * sizeof(uint32_t)) == hipSuccess; if (alloc_ok) ctx->sq_dm_words = words; }
+    if (alloc_ok && ctx->sq_nh < nh) { if (ctx->sq_hours) (void)hipFree(ctx->sq_hours); if (ctx->sq_curt) (void)hipFree(ctx->sq_curt); ctx->sq_hours = nullptr; ctx->sq_curt = nullptr; ctx->sq_nh = 0;
+                                       alloc_ok = hipMalloc(&ctx->sq_hours, nh * sizeof(uint16_t)) == hipSuccess && hipMalloc(&ctx->sq_curt, nh * sizeof(double)) == hipSuccess; if (alloc_ok) ctx->sq_nh = nh; }
+    if (alloc_ok && ctx->sq_years < n_years) {
+        for (void* q : {(void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year}) if (q) (void)hipFree(q);
+        ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr; ctx->sq_years = 0;
+        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * n_years) == hipSuccess && hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
+                   hipMalloc(&ctx->sq_year, sizeof(double) * 3 * n_years) == hipSuccess;
+        if (alloc_ok) ctx->sq_years = n_years;
+    }
+    if (!alloc_ok) return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: device allocation failed");
+    uint32_t* dm = ctx->sq_dm; uint16_t* const dhours = ctx->sq_hours; uint32_t* const dcounts = ctx->sq_counts; uint32_t* const doff = ctx->sq_off;
+    double* const dcurt = ctx->sq_curt; double* const dyear = ctx->sq_year;
+    auto cleanup = [&]() {};
+    int rc = seq_sample(ctx, seed, first_year, n_years, &dm);
+    if (rc) return rc;
+    std::vector<uint32_t> counts(n_years), off(n_years + 1, 0);
+    bool ok = hipMemsetAsync(dcurt, 0, nh * sizeof(double), ctx->stream) == hipSuccess;
+    hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, ctx->hseq.mw, dhours, dcounts);
+    ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(counts.data(), dcounts, sizeof(uint32_t) * n_years, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         hipStreamSynchronize(ctx->stream) == hipSuccess;
+    if (!ok) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: compaction failed"); }
+    for (int y = 0; y < n_years; ++y) { off[y + 1] = off[y] + counts[y]; years_out[y].n_contingency = counts[y]; }
+    const int64_t nlp = off[n_years];
+    double ms = 0.0;
+    if (nlp > 0) {
+        if (hipMemcpyAsync(doff, off.data(), sizeof(uint32_t) * (n_years + 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
+        EvalArgs a = make_args(o);
+        a.fail_threshold = curtail_threshold;
+        a.n = nlp; a.seq_masks = dm; a.seq_offsets = doff; a.seq_hours = dhours; a.load_factors = ctx->dlf; a.curt = dcurt;
+        a.seq_nyears = n_years; a.seq_hpy = hpy;
+        int blocks = 0;
+        rc = fail_arm(ctx, a, 0, true, a.n);
+        if (rc) { cleanup(); return rc; }
+        rc = launch_eval(ctx, 2, a, &blocks);
+        if (rc) { cleanup(); return rc; }
+        if (launch_finalize(ctx, blocks) != RELMC_OK || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
+        rc = finish_timing(ctx);
+        if (rc) { cleanup(); return rc; }
+        ms = ctx->last_kernel_ms;
+        RetryOut ro;                                                   // hours the primary elimination order did not converge on
+        const ScaleFn scale = [&](unsigned long long u) { return ctx->hlf[(size_t)(u % (unsigned long long)hpy)]; };
+        rc = fail_retry(ctx, o, curtail_threshold, &scale, ro, &ms);
+        if (rc) { cleanup(); return rc; }
+        for (size_t r = 0; r < ro.rec.size(); ++r) {
+            acc_add_unit(acc_out, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, curtail_threshold);
+            if (hipMemcpy(dcurt + ro.rec[r].unit, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
+        }
+    }
+    hipLaunchKernelGGL(relmc_seq_annual_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dcurt, hpy, curtail_threshold, dyear);
+    std::vector<double> yr((size_t)3 * n_years);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yr.data(), dyear, sizeof(double) * 3 * n_years, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        hipStreamSynchronize(ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: annual indices failed"); }
+    for (int y = 0; y < n_years; ++y) { years_out[y].ens = yr[3 * y]; years_out[y].dlc = yr[3 * y + 1]; years_out[y].nlc = yr[3 * y + 2]; }
+    ctx->last_kernel_ms = ms;
+    cleanup();
+    return RELMC_OK;
+}
+
+// ---- HL1 copper sheet: PowerSystemAdequacy.jl:169-208 --------------------------------------------------
+int32_t relmc_hl1_load(relmc_ctx* ctx, int32_t ngen, const double* capacity_mw, const double* for_rate, int32_t nhours,
+                       const double* hourly_load_mw)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!capacity_mw || !for_rate || !hourly_load_mw || ngen < 1 || nhours < 1) return fail(ctx, RELMC_ERR_INVALID, "relmc_hl1_load: bad arguments");
+    if (ngen > NCOMPMAX) return fail(ctx, RELMC_ERR_UNSUPPORTED, "relmc_hl1_load: more than 128 units");
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    Hl1Case h; std::memset(&h, 0, sizeof(h));
+    h.ngen = ngen; h.nhours = nhours;
+    for (int g = 0; g < ngen; ++g) {
+        double t = std::floor(for_rate[g] * 4294967296.0);
+        if (!(t > 0)) t = 0;
+        if (t > 4294967295.0) t = 4294967295.0;
+        h.thr[g] = (uint32_t)t; h.cap[g] = capacity_mw[g];
+    }
+    std::vector<double> sorted(hourly_load_mw, hourly_load_mw + nhours), suffix(nhours + 1, 0.0);
+    std::sort(sorted.begin(), sorted.end());
+    for (int k = nhours - 1; k >= 0; --k) suffix[k] = suffix[k + 1] + sorted[k];
+    if (ctx->dsorted) (void)hipFree(ctx->dsorted);
+    if (ctx->dsuffix) (void)hipFree(ctx->dsuffix);
+    ctx->dsorted = ctx->dsuffix = nullptr;
+    if (!ctx->dhl1) HIP_TRY(ctx, hipMalloc(&ctx->dhl1, sizeof(Hl1Case)));
+    HIP_TRY(ctx, hipMalloc(&ctx->dsorted, sizeof(double) * nhours));
+    HIP_TRY(ctx, hipMalloc(&ctx->dsuffix, sizeof(double) * (nhours + 1)));
+    HIP_TRY(ctx, hipMemcpy(ctx->dhl1, &h, sizeof(h), hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dsorted, sorted.data(), sizeof(double) * nhours, hipMemcpyHostToDevice));
+    HIP_TRY(ctx, hipMemcpy(ctx->dsuffix, suffix.data(), sizeof(double) * (nhours + 1), hipMemcpyHostToDevice));
+    ctx->hl1_hours = nhours; ctx->has_hl1 = true;
+    return RELMC_OK;
+}
+
+int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n, relmc_hl1_acc* acc, double* iter_lole_host,
+                      double* iter_eue_host)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_hl1) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_hl1_nsq: relmc_hl1_load has not been called");
+    if (n < 0 || !acc) return fail(ctx, RELMC_ERR_INVALID, "relmc_hl1_nsq: bad arguments");
+    std::memset(acc, 0, sizeof(*acc));
+    if (n == 0) return RELMC_OK;
+    HIP_TRY(ctx, hipSetDevice(ctx->device));
+    int64_t blocks = (n + 255) / 256;
+    if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
+    double *dl = nullptr, *de = nullptr, *dpart = nullptr;
+    int rc = RELMC_OK;
+    auto cleanup = [&]() { (void)hipFree(dl); (void)hipFree(de); (void)hipFree(dpart); };
+    if ((iter_lole_host && hipMalloc(&dl, sizeof(double) * n) != hipSuccess) || (iter_eue_host && hipMalloc(&de, sizeof(double) * n) != hipSuccess) ||
+        hipMalloc(&dpart, sizeof(double) * 4 * blocks) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: device allocation failed"); }
+    (void)hipEventRecord(ctx->ev0, ctx->stream);
+    hipLaunchKernelGGL(relmc_hl1_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->dhl1, ctx->dsorted, ctx->dsuffix, seed,
+                       first_index, n, dl, de, dpart);
+    (void)hipEventRecord(ctx->ev1, ctx->stream);
+    std::vector<double> part((size_t)4 * blocks);
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, sizeof(double) * 4 * blocks, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+        finish_timing(ctx) != RELMC_OK) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: launch failed");
+    if (rc == RELMC_OK && iter_lole_host && hipMemcpy(iter_lole_host, dl, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    if (rc == RELMC_OK && iter_eue_host && hipMemcpy(iter_eue_host, de, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    cleanup();
+    if (rc) return rc;
+    acc->n = n;
+    for (int64_t b = 0; b < blocks; ++b) { acc->sum_lole += part[4 * b]; acc->sum_eue += part[4 * b + 1]; acc->sum_lole2 += part[4 * b + 2]; acc->sum_eue2 += part[4 * b + 3]; }
+    return RELMC_OK;
+}
+
+}  // extern "C"

@@ -22,7 +22,7 @@ def graph(c):
 
 
 def shipped_rule(adj, ref):
-    """level first, then fill, then degree, then bus number: case_symbolic's key (relmc_abi.hip)"""
+    """level first, then fill, then degree, then bus number: case_symbolic's key (csrc/relmc_schedule.hip)"""
     n = len(adj); A = [set(s) for s in adj]; gone = [False] * n; level = [-1] * n; order = []
     for step in range(n):
         best = None

@@ -1,6 +1,6 @@
 """CPU interpreter of the static solver schedule (test infrastructure, no GPU).
 
-`relmc_debug_symbolic` (csrc/relmc_abi.hip) runs the host-side symbolic analysis of `relmc_case_load` without a device and hands
+`relmc_debug_symbolic` (csrc/relmc_schedule.hip) runs the host-side symbolic analysis of `relmc_case_load` without a device and hands
 back the pass program the evaluation kernel interprets.  `solve()` executes that program with numpy on one bus-pair system
 [[M, B'], [B, -E]] in exactly the kernel's data layout (2x2 blocks in a flat workspace W, the right-hand side as a pseudo bus)
 and returns the solution, which the tests compare with numpy.linalg.solve on the dense matrix.  Every pass form is covered:
@@ -51,12 +51,12 @@ class Schedule:
         return self.npass - self.npass_upd - self.npass_inv
 
 
-def symbolic(case, order_variant: int = 0, order=None) -> Schedule:
+def symbolic(case, order_variant: int = 0, order=None, model_leaf_free: int = -1) -> Schedule:
     L = _lib.load()
     f = L.relmc_debug_symbolic
     f.restype = C.c_int32
     f.argtypes = [C.c_void_p, C.c_int32, C.c_void_p, C.c_int32, C.c_void_p, C.c_void_p, C.c_int64, C.c_void_p, C.c_void_p, C.c_void_p, C.c_void_p,
-                  C.c_void_p, C.c_char_p, C.c_int32]
+                  C.c_void_p, C.c_char_p, C.c_int32, C.c_int32]
     hint = None if order is None else np.ascontiguousarray(order, dtype=np.int32)
     holder = _abi.CaseHolder(case)
     hdr = np.zeros(24, np.int32)
@@ -68,7 +68,7 @@ def symbolic(case, order_variant: int = 0, order=None) -> Schedule:
     zero_off = np.zeros(512, np.uint16)
     err = C.create_string_buffer(512)
     rc = f(C.byref(holder.desc), order_variant, None if hint is None else hint.ctypes.data, 0 if hint is None else int(hint.size), hdr.ctypes.data, tasks.ctypes.data, tasks.size, pnt.ctypes.data, b_int.ctypes.data,
-           l_blk.ctypes.data, l_info.ctypes.data, zero_off.ctypes.data, err, 512)
+           l_blk.ctypes.data, l_info.ctypes.data, zero_off.ctypes.data, err, 512, int(model_leaf_free))
     if rc != 0:
         raise RuntimeError(f"relmc_debug_symbolic failed ({rc}): {err.value.decode()}")
     h = [int(x) for x in hdr]
