@@ -52,11 +52,15 @@ def main():
                     help="nsq24 = BASELINE configs[1] (the headline, default); rts96 = configs[4] shape; seq = configs[3] shape")
     ap.add_argument("--years", type=int, default=125, help="seq workload: simulated years per GPU per step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--comm", choices=["torch", "native", "host"], default="torch",
-                    help="who all-reduces relmc_acc: torch.distributed (default); native = the library's own RCCL communicator (relmc_comm_*: the "
-                         "128-byte id travels over a gloo group, torch holds NO nccl group in the process); host = torch's collective registered "
+    ap.add_argument("--comm", choices=["native", "torch", "host"], default="native",
+                    help="who all-reduces relmc_acc when N > 1: native (default) = the library's own RCCL communicator (relmc_comm_*: the north star's "
+                         "single RCCL all-reduce over xGMI, no host staging; the 128-byte id travels over a gloo group, torch holds NO nccl group in the "
+                         "process: one RCCL user); torch = torch.distributed's collective on the process group; host = torch's collective registered "
                          "with the library as the host transport (relmc_comm_set_host_allreduce).  native / host run the multi-rank nsqMain loop "
                          "below the C ABI (relmc_nsq_run)")
+    ap.add_argument("--comm-timeout", type=float, default=120.0, help="wall-clock guard (seconds) of communicator init and of every collective: on expiry the "
+                                                                       "rank prints who it is and what it waited for and exits non-zero (0 = off)")
+    ap.add_argument("--no-secondary", action="store_true", help="skip the RTS-96 / sequential / HL1 rates measured beside the headline (outside the timed region)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
@@ -85,11 +89,13 @@ def main():
     # --comm native: ONE RCCL user in the process (the library's communicator), so torch gets a gloo group for the rendezvous,
     # the barriers and the max over ranks of the elapsed time
     pg_backend = "gloo" if args.comm == "native" else args.backend
+    guard = lambda what: rdist.Watchdog(args.comm_timeout, what, rank=rank, world=world, device=local_rank)
     if world > 1:
-        if pg_backend == "nccl":
-            dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-        else:
-            dist.init_process_group(pg_backend, rank=rank, world_size=world)
+        with guard(f"torch.distributed.init_process_group({pg_backend})"):
+            if pg_backend == "nccl":
+                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+            else:
+                dist.init_process_group(pg_backend, rank=rank, world_size=world)
 
     def sync():
         if world > 1:
@@ -104,6 +110,7 @@ def main():
     else:
         case = case24.rts24()
     eng = api.Engine(case, device=local_rank)
+    eng.comm_set_timeout(args.comm_timeout)
     comm = None
     if world > 1 and args.comm != "torch":
         try:
@@ -117,9 +124,26 @@ def main():
 
     def allreduce(acc):
         t_ = time.perf_counter()
-        out_ = comm.allreduce_acc(acc) if comm is not None else rdist.allreduce_acc(acc, device)
+        if comm is not None:
+            out_ = comm.allreduce_acc(acc)                       # guarded inside the library (relmc_comm_set_timeout)
+        elif world > 1:
+            with guard("torch.distributed.all_reduce of relmc_acc"):
+                out_ = rdist.allreduce_acc(acc, device)
+        else:
+            out_ = acc
         ar_seconds[0] += time.perf_counter() - t_; ar_calls[0] += 1
         return out_
+
+    # which GPU every rank drives (PCI bus id from the library's own context): the line proves N DISTINCT devices
+    devices = [eng.pci_bus_id()]
+    if world > 1:
+        box_ = [None] * world
+        with guard("all_gather of the ranks' PCI bus ids"):
+            dist.all_gather_object(box_, devices[0])
+        devices = [str(x) for x in box_]
+        if len(set(devices)) != world and not args.share_device:
+            print(f"bench.py: rank {rank}: the {world} ranks drive only {len(set(devices))} distinct GPUs: {devices}", file=sys.stderr, flush=True)
+            sys.exit(5)
 
     B = args.batch
     if args.workload in ("nsq24", "rts96"):
@@ -149,7 +173,12 @@ def main():
         def step(k):
             e, d, n_, ncont, acc = sq.seq_years(args.seed, (k * world + rank) * Y, Y)
             ms = eng.last_kernel_ms()
-            rdist.allgather_years(np.column_stack([e, d, n_]), [Y] * world, device)
+            trip = np.column_stack([e, d, n_])
+            if comm is not None:
+                comm.allgather_rows(trip, [Y] * world)          # relmc_comm_allreduce_f64: every rank fills its own rows of a zeroed matrix
+            elif world > 1:
+                with guard("torch.distributed.all_gather of the annual indices"):
+                    rdist.allgather_years(trip, [Y] * world, device)
             return allreduce(acc), ms, int(acc.n)
         unit, metric = "hourly DC-OPFs/s", "Monte Carlo hourly DC-OPF evaluations/sec (RTS-24 HL2 sequential)"
         workload = f"HL2 sequential MCS, RTS-24, {Y} simulated years x 8736 h per GPU per step, contingency hours only (BASELINE configs[3] shape)"
@@ -184,6 +213,8 @@ def main():
         comm_info = {"backend": ("torch-" + pg_backend) if world > 1 else "none", "nranks_seen": dist.get_world_size() if world > 1 else 1,
                      "allreduce_calls": ar_calls[0] if world > 1 else 0, "allreduce_us_avg": (1e6 * ar_seconds[0] / max(1, ar_calls[0])) if world > 1 else 0.0}
     comm_info["allreduce_bytes"] = _C.sizeof(_rabi.Acc)
+    comm_info["devices"] = devices
+    comm_info["timeout_s"] = args.comm_timeout
     if comm_info["nranks_seen"] != world:
         print(f"bench.py: rank {rank}: the communicator reports {comm_info['nranks_seen']} ranks, the launcher {world}", file=sys.stderr, flush=True)
         sys.exit(4)
@@ -271,6 +302,8 @@ def main():
                 "time_to_cov_1pct_seconds": dt1, "samples": r1.current_iteration, "beta": r1.current_beta, "rows": r1.database_row_count,
                 "time_to_reference_beta_limit_0.0017": {"seconds": dt2, "samples": r2.current_iteration, "beta": r2.current_beta,
                                                         "rows": r2.database_row_count, "edns_mw": r2.accumulated_edns}}
+        if world == 1 and args.workload == "nsq24" and not args.no_secondary:
+            out["secondary"] = secondary_workloads(eng, local_rank, opts, args.seed)
         if world == 1 and not args.no_cpu_baseline and args.workload == "nsq24":
             out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
         if args.dump_acc:
@@ -282,6 +315,62 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+
+
+def secondary_workloads(eng24, device, opts, seed, steps=3):
+    """The other BASELINE.json configs on this GPU, measured OUTSIDE the timed region (1 warm-up + `steps` steps each, wall-clocked between
+    synchronisations like the headline): configs[4] shape (RTS-96, 1e6 samples per step), configs[3] shape (sequential RTS-24, 125 years x 8736 h
+    per step = the contingency hours' DC-OPFs), configs[0] (HL1 copper sheet, 1e5 iterations x 8736-h load curve per step)."""
+    import numpy as np
+    import torch
+    from powersystemsreliabilityassessment_amd import api, case96, hl1, seq as rseq
+    res = {}
+
+    def timed(fn):
+        fn(0)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); outs = []; kms = []
+        for k in range(1, steps + 1):
+            outs.append(fn(k)); kms.append(eng_cur[0].last_kernel_ms())
+        torch.cuda.synchronize()
+        return outs, (time.perf_counter() - t0) / steps, sum(kms) / len(kms)
+
+    def line(eng, case, accs, dt, kms, units, unit, workload, kernel):
+        n = sum(int(a.n) for a in accs); it = sum(int(a.sum_iters) for a in accs)
+        mean_it = it / max(1, n)
+        fl = sparse_flop_per_iteration(eng, case)
+        ach = (n / len(accs)) * mean_it * fl / (kms * 1e-3) / 1e12
+        return {"workload": workload, "value": units / dt, "unit": unit, "ms_per_step": dt * 1e3, "kernel": kernel, "kernel_ms_avg": kms, "steps": steps,
+                "mean_ipm_iterations": mean_it, "flop_per_iteration_executed": fl, "achieved_tflops_executed": ach, "frac_executed": ach / FP64_PEAK_TFLOPS,
+                "n_nonconverged": sum(int(a.n_nonconverged) for a in accs), "solver_schedule": schedule_summary(eng, case)}
+
+    # configs[4] shape: RTS-96
+    c96 = case96.rts96()
+    e96 = api.Engine(c96, device=device)
+    eng_cur = [e96]
+    B = 1_000_000
+    accs, dt, kms = timed(lambda k: e96.nsq_accumulate(seed, k * B, B, opts))
+    res["rts96"] = line(e96, c96, accs, dt, kms, B, "scenarios/s", f"HL2 non-sequential MCS, IEEE RTS-96 DC-OPF load shedding, {B} samples per step (BASELINE configs[4] shape)",
+                        "relmc_eval_kernel<0, Tile96>")
+    e96.close()
+    # configs[3] shape: sequential RTS-24
+    sq = rseq.SeqEngine(eng24)
+    eng_cur = [eng24]
+    Y = 125
+    outs, dt, kms = timed(lambda k: sq.seq_years(seed, k * Y, Y, opts)[4])
+    lp = sum(int(a.n) for a in outs) / len(outs)
+    res["seq"] = line(eng24, eng24.case, outs, dt, kms, lp, "hourly DC-OPFs/s", f"HL2 sequential MCS, RTS-24, {Y} simulated years x 8736 h per step, contingency hours only "
+                      "(BASELINE configs[3] shape)", "relmc_eval_kernel<2, Tile24>")
+    res["seq"]["years_per_s"] = Y / dt
+    # configs[0]: HL1 copper sheet (GeneratingAdequacy path): one fleet state per iteration swept over the 8736-h load curve
+    gens, load = hl1.rts24_generators(), hl1.rts24_load()
+    N1 = 100_000
+    rs, dt, kms = timed(lambda k: hl1.run_non_sequential_mc(gens, load, N1, seed=seed + k, engine=eng24))
+    res["hl1"] = {"workload": f"HL1 copper-sheet non-sequential MCS on IEEE RTS-24, {N1} iterations x 8736-h load curve per step (BASELINE configs[0])",
+                  "value": N1 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3, "kernel": "relmc_hl1_kernel", "kernel_ms_avg": kms, "steps": steps,
+                  "lole_h_per_yr": float(np.mean([r.lole_hours_yr for r in rs])), "eue_mwh_per_yr": float(np.mean([r.eue_mwh_yr for r in rs])),
+                  "exact_lole_eue": [9.3941, 1176.29], "includes": "per-iteration LOLE history copied to the host (the reference's convergence history, :202-204)"}
+    return res
 
 
 def schedule_summary(eng, case):
@@ -378,7 +467,22 @@ def cpu_baseline(case, policy, seed, n_sample):
     t2 = time.perf_counter()
     d = orc.nsq_database(seed, 0.01, 5_000_000, 100, policy=policy, nthreads=cores, max_rows=200_000)
     dt2 = time.perf_counter() - t2
+    model = ""
+    try:
+        for ln in open("/proc/cpuinfo"):
+            if ln.startswith("model name"):
+                model = ln.split(":", 1)[1].strip(); break
+    except OSError:
+        pass
+    try:
+        load1 = os.getloadavg()[0]
+    except OSError:
+        load1 = None
     return {"value": n / dt, "unit": "scenarios/s", "cores": cores, "kind": "port", "single_core_value": n1 / dt1, "cpu_quota": quota,
+            "box": {"cpu_model": model, "cpus_visible": os.cpu_count(), "affinity": len(os.sched_getaffinity(0)), "cgroup_quota_cpus": quota, "loadavg_1min_before": load1,
+                    "threads_used": cores, "per_thread_value": n / dt / cores,
+                    "note": "the box is shared: the granted cores run at whatever clock and cache share the neighbours leave (round 2: 43.3 k/s, round 3: 36.2 k/s on the same "
+                            "16 granted threads); single_core_value x threads bounds what contention took"},
             "sample": f"first {n} scenarios of the same seed, every scenario solved (no state memo), "
                       f"{dt:.1f} s on {cores} OpenMP threads (host CPUs visible {os.cpu_count()}, cgroup quota {quota})",
             "edns_mw": acc.sum_dns / acc.n,

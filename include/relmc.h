@@ -307,6 +307,7 @@ int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64
  * relmc_seq_mcsampling    <- seq_mcsampling(reliability_data, Ng, Nl, 1, hours) per year (seq_mcsampling.m:2;
  *                            every year starts all-up as seqMain.m:91): out[years][hours][ng+nl], 1 = down
  * relmc_seq_mcsimulation  <- [curt, nodal] = seq_mcsimulation(status, load_scale, ...) (seq_mcsimulation.m:1), batched
+ * relmc_seq_run           <- the loop itself with its stopping rule and post-processing, seqMain.m:85-249 (below)
  * relmc_seq_years         <- the body of seqMain.m:85-176 for a range of simulated years, fused on the GPU:
  *                            chronology -> contingency hours (:97) -> DC-OPF per hour (:112-133) -> annual
  *                            indices (:160-176, calnlc.m) + the post-processing accumulators (:142-158)     */
@@ -328,6 +329,42 @@ int32_t relmc_seq_mcsimulation(relmc_ctx* ctx, const uint8_t* states_host, const
 int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int32_t n_years,
                         const relmc_solver_opts* opts, double curtail_threshold, relmc_seq_year* years_out,
                         relmc_acc* acc_out);
+
+/* relmc_seq_run <- the whole yearly loop of seqMain.m:85-199 (CoV stop at :194) and its post-processing :211-249, below the C ABI like
+ * relmc_nsq_run.  With a communicator of more than one rank in the context (relmc_comm_init / relmc_comm_set_host_allreduce) it IS the
+ * multi-rank loop: the years of every batch shard contiguously over the ranks, the annual triples are all-gathered in year order, every rank
+ * stops at the same year and returns the same result.  The years depend on (seed, global year) only: results_year, the stopping year and every
+ * integer of the accumulators do not depend on the number of ranks or on batch_years. */
+typedef struct {
+    double cov_threshold;     /* seqMain.m:40 (0.05) */
+    int32_t max_years;        /* seqMain.m:39 (4000) */
+    int32_t batch_years;      /* simulated years per launch round over all ranks; 0 = 64 per rank */
+    uint64_t seed;
+    double curtail_threshold; /* seqMain.m:41 (0.01 MW) */
+    relmc_solver_opts solver;
+    /* optional history buffers (may be NULL), each with room for years_cap >= max_years entries */
+    int64_t years_cap;
+    relmc_seq_year* results_year;   /* results_year.ens / dlc / nlc (+ contingency hours), seqMain.m:162-176 */
+    double* cum_eens;               /* results_cum.eens, :180 */
+    double* cum_cov;                /* results_cum.cov, :183-185 (entry 0 = 0 as in the reference) */
+} relmc_seq_opts;
+typedef struct {
+    int32_t final_year;       /* years simulated = the stopping year (seqMain.m:203) */
+    int32_t converged;        /* CoV < cov_threshold reached (:194) */
+    double eens;              /* MWh/yr, results_cum.eens(end)     */
+    double cov;               /* results_cum.cov(end)              */
+    double lole;              /* h/yr, mean(results_year.dlc), :212 */
+    double lolf;              /* occ/yr, mean(results_year.nlc), :213 */
+    double plc;               /* mean(results_year.plc)            */
+    int64_t n_contingency;    /* contingency hours of the years 1..final_year (= hourly OPFs the run stands for) */
+    relmc_acc acc;            /* accumulators over exactly the years 1..final_year: n = hourly OPFs, n_fail = loss hours (total_loss_hours, :158),
+                                 comp_fail (:155), sum_nodal in MWh (:149) */
+    double nodal_eens_avg[RELMC_MAX_BUS];      /* MWh/yr, :218 */
+    double comp_importance[RELMC_MAX_COMP];    /* P(component down | loss hour), :233 */
+    double wall_seconds, kernel_seconds;
+} relmc_seq_result;
+void relmc_seq_opts_default(relmc_seq_opts* opts);
+int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* opts, relmc_seq_result* result);
 
 /* Units (samples, states, database rows) that the solver's static elimination order ends non-converged (status MAXIT or NUMFAIL;
  * 6.7e-7 of the RTS-96 scenarios, 4e-10 on RTS-24) are evaluated again under further static orders by every entry point, the
@@ -360,6 +397,9 @@ int32_t relmc_case_order(const relmc_ctx* ctx, int32_t* primary_out, int32_t pro
  *                          bus numbers in elimination order, the reference bus last; stats_out (optional) = {LDS instructions per Newton step,
  *                          dependent passes} of the start order and of the result.  An order never changes WHAT is computed, only the
  *                          rounding of the factorisation (iteration counts of single states may move by one).
+ *                          The figures quoted above are those of the orders tuned for RTS-24 / RTS-96, which the hosts ship with their case data
+ *                          (case24.RTS24_ELIM_ORDER / case96.RTS96_ELIM_ORDER, the same constants in julia/RelMC.jl); a host that passes no hint --
+ *                          a plain C client -- runs the rule's order: same results to the solver's tolerances, another rounding.
  *   relmc_case_order_hint  the order for the NEXT relmc_case_load of this context (copied; NULL / 0 = the rule); the load fails with
  *                          RELMC_ERR_INVALID if it is not a permutation of 0..nb-1 with the reference bus last.  The further orders of
  *                          the retry path (relmc_retry_stats) stay rule-made. */

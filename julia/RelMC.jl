@@ -87,6 +87,13 @@ end
 
 check(rc, h, what) = rc == 0 || error("$what failed ($rc): " * unsafe_string(ccall((:relmc_last_error, LIB), Cstring, (Ptr{Cvoid},), h)))
 
+# The primary elimination orders this package ships for the two IEEE test systems (0-based bus numbers, reference bus last; tuned offline with
+# relmc_tune_order, identical to case24.RTS24_ELIM_ORDER / case96.RTS96_ELIM_ORDER of the Python host, so that every host runs the same pass
+# program -- an order changes the rounding of the factorisation: iteration counts of single states may move by one, DESIGN.md 3.2).
+# Pass them as `Engine(sys; elim_order=RTS24_ELIM_ORDER)`; without a hint the library's rule decides.
+const RTS24_ELIM_ORDER = Int32[4, 21, 18, 5, 19, 17, 3, 6, 22, 23, 1, 20, 2, 11, 13, 16, 10, 0, 14, 15, 7, 8, 9, 12]
+const RTS96_ELIM_ORDER = Int32[69, 41, 27, 3, 61, 2, 67, 42, 4, 17, 47, 60, 11, 53, 66, 18, 36, 54, 43, 5, 52, 71, 24, 51, 59, 64, 30, 44, 21, 6, 62, 29, 37, 14, 58, 48, 35, 55, 7, 49, 28, 68, 1, 34, 13, 25, 19, 31, 45, 40, 23, 56, 16, 38, 72, 65, 0, 57, 10, 33, 32, 39, 63, 15, 50, 9, 8, 70, 26, 22, 20, 46, 12]
+
 # `elim_order`: optional primary elimination order of the device solver's static schedule (0-based bus numbers, the reference bus last),
 # e.g. one found by `tune_order` below; `nothing` = the library's rule (relmc_case_order_hint).
 function Engine(sys::TestSystem; device::Integer=0, elim_order::Union{Nothing,Vector{Int32}}=nothing)
@@ -375,27 +382,44 @@ function seq_years(eng::Engine, seed::Integer, first_year::Integer, n_years::Int
     return yrs, acc
 end
 
-"seqMain (seqMain.m:85-262): annual indices until CoV(EENS) < cov_threshold."
-function seqMain(eng::Engine; max_sim_years=4000, cov_threshold=0.05, seed=1, mpopt=mpoption(), batch_years=64)
-    ens = Float64[]; dlc = Float64[]; nlc = Float64[]; cum_eens = Float64[]; cum_cov = Float64[]
-    done = 0; stop = false
-    while done < max_sim_years && !stop
-        m = min(batch_years, max_sim_years - done)
-        yrs, _ = seq_years(eng, seed, done, m, mpopt)
-        for y in yrs
-            push!(ens, y.ens); push!(dlc, y.dlc); push!(nlc, y.nlc)
-            k = length(ens); mu = sum(ens) / k
-            cov = (k > 1 && mu > 0) ? sqrt(sum((ens .- mu) .^ 2) / (k - 1)) / (mu * sqrt(k)) : 0.0     # seqMain.m:183-185
-            push!(cum_eens, mu); push!(cum_cov, cov)
-            if k > 1 && 0 < cov < cov_threshold                                                   # :194
-                stop = true; break
-            end
-        end
-        done += m
+"relmc_seq_opts (include/relmc.h): the options of the whole seqMain loop"
+struct SeqOpts
+    cov_threshold::Cdouble; max_years::Int32; batch_years::Int32; seed::UInt64; curtail_threshold::Cdouble
+    solver::SolverOptsC
+    years_cap::Int64
+    results_year::Ptr{SeqYear}; cum_eens::Ptr{Cdouble}; cum_cov::Ptr{Cdouble}
+end
+
+# relmc_seq_result is read out of a byte buffer at these offsets (like relmc_nsq_result)
+const SEQ_RESULT_ACC = 56                                                   # final_year, converged, eens, cov, lole, lolf, plc, n_contingency
+const SEQ_RESULT_NODAL = SEQ_RESULT_ACC + 8 * (6 + MAX_COMP + 2 + MAX_BUS)
+const SEQ_RESULT_IMP = SEQ_RESULT_NODAL + 8 * MAX_BUS
+const SEQ_RESULT_TAIL = SEQ_RESULT_IMP + 8 * MAX_COMP                       # wall_seconds, kernel_seconds
+const SEQ_RESULT_BYTES = SEQ_RESULT_TAIL + 16
+
+"""
+seqMain (seqMain.m:85-262): annual indices until CoV(EENS) < cov_threshold, then LOLE / LOLF, nodal EENS (:218) and component importance
+(:233).  The loop, its stopping rule and the post-processing run below the C ABI (relmc_seq_run); with a communicator in the engine's
+context the same call on every rank is the multi-rank run.
+"""
+function seqMain(eng::Engine; max_sim_years=4000, cov_threshold=0.05, curtail_threshold=0.01, seed=1, mpopt=mpoption(), batch_years=0)
+    yrs = Vector{SeqYear}(undef, max_sim_years); cum_eens = zeros(Float64, max_sim_years); cum_cov = zeros(Float64, max_sim_years)
+    buf = zeros(UInt8, SEQ_RESULT_BYTES)
+    acc = Acc()
+    GC.@preserve yrs cum_eens cum_cov buf acc begin
+        o = SeqOpts(cov_threshold, max_sim_years, batch_years, seed, curtail_threshold, SolverOptsC(mpopt), max_sim_years,
+                    pointer(yrs), pointer(cum_eens), pointer(cum_cov))
+        check(ccall((:relmc_seq_run, LIB), Int32, (Ptr{Cvoid}, Ref{SeqOpts}, Ptr{UInt8}), eng.h, Ref(o), buf), eng.h, "relmc_seq_run")
+        unsafe_copyto!(Ptr{UInt8}(pointer_from_objref(acc)), pointer(buf) + SEQ_RESULT_ACC, SEQ_RESULT_NODAL - SEQ_RESULT_ACC)
     end
-    k = length(ens)
-    return (final_year=k, eens=cum_eens[end], cov=cum_cov[end], lole=sum(dlc[1:k]) / k, lolf=sum(nlc[1:k]) / k,
-            results_year=(ens=ens, dlc=dlc, nlc=nlc), results_cum=(eens=cum_eens, cov=cum_cov))
+    rd(T, off) = GC.@preserve buf unsafe_load(Ptr{T}(pointer(buf) + off))
+    k = Int(rd(Int32, 0)); nb = eng.sys.nb; nc = eng.sys.ng + eng.sys.nl
+    resize!(yrs, k); resize!(cum_eens, k); resize!(cum_cov, k)
+    return (final_year=k, converged=rd(Int32, 4) != 0, eens=rd(Cdouble, 8), cov=rd(Cdouble, 16), lole=rd(Cdouble, 24), lolf=rd(Cdouble, 32),
+            results_year=(ens=[y.ens for y in yrs], dlc=[y.dlc for y in yrs], nlc=[y.nlc for y in yrs]), results_cum=(eens=cum_eens, cov=cum_cov),
+            nodal_eens_avg=[rd(Cdouble, SEQ_RESULT_NODAL + 8 * (i - 1)) for i in 1:nb],
+            comp_importance=[rd(Cdouble, SEQ_RESULT_IMP + 8 * (i - 1)) for i in 1:nc],
+            total_loss_hours=acc.n_fail, n_lp=acc.n, elapsed_time=rd(Cdouble, SEQ_RESULT_TAIL), kernel_seconds=rd(Cdouble, SEQ_RESULT_TAIL + 8))
 end
 
 mutable struct Hl1Acc
@@ -426,6 +450,8 @@ const LAYOUT = [
     ("relmc_seq_year", 32, [("ens", 0), ("dlc", 8), ("nlc", 16), ("n_contingency", 24)]),
     ("relmc_hl1_acc", 40, [("n", 0), ("sum_lole", 8), ("sum_eue2", 32)]),
     ("relmc_nsq_opts", 168, [("beta_limit", 0), ("max_samples", 8), ("batch", 16), ("seed", 24), ("hours_per_year", 32), ("solver", 40), ("history_cap", 120), ("beta_history", 128), ("plc_history", 152), ("distinct_states", 160)]),
+    ("relmc_seq_opts", 144, [("cov_threshold", 0), ("max_years", 8), ("batch_years", 12), ("seed", 16), ("curtail_threshold", 24), ("solver", 32), ("years_cap", 112), ("results_year", 120), ("cum_cov", 136)]),
+    ("relmc_seq_result", SEQ_RESULT_BYTES, [("final_year", 0), ("converged", 4), ("eens", 8), ("plc", 40), ("n_contingency", 48), ("acc", SEQ_RESULT_ACC), ("nodal_eens_avg", SEQ_RESULT_NODAL), ("comp_importance", SEQ_RESULT_IMP), ("wall_seconds", SEQ_RESULT_TAIL), ("kernel_seconds", SEQ_RESULT_TAIL + 8)]),
     ("relmc_nsq_result", NSQ_RESULT_BYTES, [("acc", 0), ("idx", NSQ_RESULT_IDX), ("checkpoints", NSQ_RESULT_TAIL), ("converged", NSQ_RESULT_TAIL + 8), ("wall_seconds", NSQ_RESULT_TAIL + 16), ("kernel_seconds", NSQ_RESULT_TAIL + 24), ("batches", NSQ_RESULT_TAIL + 32)]),
 ]
 

@@ -111,6 +111,28 @@ class NsqResult(C.Structure):
     ]
 
 
+class SeqYear(C.Structure):
+    _fields_ = [("ens", C.c_double), ("dlc", C.c_double), ("nlc", C.c_double), ("n_contingency", C.c_int64)]
+
+
+class SeqOpts(C.Structure):
+    _fields_ = [
+        ("cov_threshold", C.c_double), ("max_years", C.c_int32), ("batch_years", C.c_int32), ("seed", C.c_uint64),
+        ("curtail_threshold", C.c_double), ("solver", SolverOpts),
+        ("years_cap", C.c_int64), ("results_year", C.POINTER(SeqYear)), ("cum_eens", c_double_p), ("cum_cov", c_double_p),
+    ]
+
+
+class SeqResult(C.Structure):
+    _fields_ = [
+        ("final_year", C.c_int32), ("converged", C.c_int32),
+        ("eens", C.c_double), ("cov", C.c_double), ("lole", C.c_double), ("lolf", C.c_double), ("plc", C.c_double),
+        ("n_contingency", C.c_int64), ("acc", Acc),
+        ("nodal_eens_avg", C.c_double * RELMC_MAX_BUS), ("comp_importance", C.c_double * RELMC_MAX_COMP),
+        ("wall_seconds", C.c_double), ("kernel_seconds", C.c_double),
+    ]
+
+
 class DbStats(C.Structure):
     _fields_ = [("rows", C.c_int64), ("samples", C.c_int64), ("new_rows", C.c_int64), ("batch_distinct", C.c_int64)]
 

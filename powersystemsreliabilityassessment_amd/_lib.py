@@ -27,7 +27,7 @@ EXPORTS = [
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_retry_dense_stats", "relmc_case_order",
     "relmc_case_order_hint", "relmc_tune_order",
-    "relmc_comm_set_timeout", "relmc_comm_allreduce_f64", "relmc_device_pci_bus_id",
+    "relmc_comm_set_timeout", "relmc_comm_allreduce_f64", "relmc_device_pci_bus_id", "relmc_seq_opts_default", "relmc_seq_run",
 ]
 
 

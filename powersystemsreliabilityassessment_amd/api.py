@@ -381,6 +381,20 @@ class Engine:
                                            its.ctypes.data_as(_abi.c_int32_p) if its is not None else None,
                                            rel.ctypes.data_as(_abi.c_uint8_p) if rel is not None else None), "relmc_db_import")
 
+    def comm_set_timeout(self, seconds: float):
+        """relmc_comm_set_timeout: wall-clock guard of communicator init and of every collective through this context (<= 0: off)."""
+        self._check(self.L.relmc_comm_set_timeout(self._h, float(seconds)), "relmc_comm_set_timeout")
+
+    def pci_bus_id(self) -> str:
+        """PCI bus id of the GPU this context drives (relmc_device_pci_bus_id)."""
+        buf = C.create_string_buffer(64)
+        self._check(self.L.relmc_device_pci_bus_id(self._h, buf, 64), "relmc_device_pci_bus_id")
+        return buf.value.decode()
+
+    def debug_set(self, key: str, value: bool = True):
+        """Diagnosis switch of the context (tests): no_retry, retry_dense_first, nsq_no_stretch, db_no_probe (relmc_debug_set)."""
+        self._check(self.L.relmc_debug_set(self._h, key.encode(), int(bool(value))), "relmc_debug_set")
+
     def last_kernel_ms(self) -> float:
         ms = C.c_double()
         self._check(self.L.relmc_last_kernel_ms(self._h, C.byref(ms)), "relmc_last_kernel_ms")

@@ -178,6 +178,117 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     return RELMC_OK;
 }
 
+void relmc_seq_opts_default(relmc_seq_opts* o)
+{
+    if (!o) return;
+    std::memset(o, 0, sizeof(*o));
+    o->cov_threshold = 0.05;      /* seqMain.m:40 */
+    o->max_years = 4000;          /* seqMain.m:39 */
+    o->curtail_threshold = 0.01;  /* seqMain.m:41 */
+    o->batch_years = 0;           /* 64 per rank */
+    o->seed = 1;
+    relmc_solver_opts_default(&o->solver);
+}
+
+// seqMain.m:85-199 (the yearly loop with its CoV stop) + :211-249 (LOLE / LOLF, nodal EENS, component importance), single- and multi-rank.
+// Years are independent streams keyed by (seed, global year) and every year starts all-up (seqMain.m:91 samples ONE year per call), so the
+// years [done, done + m) of a batch are split contiguously over the ranks of the context's communicator; the annual (ens, dlc, nlc) triples are
+// all-gathered in year order (a sum all-reduce of a vector in which every rank fills its own slots), every rank walks the same CoV curve
+// (:180-185) and stops at the same year (:194); the post-processing accumulators (:146-159) cover exactly the years up to the stopping year --
+// the batch it falls into is evaluated again over its used part -- and are all-reduced once per batch.
+int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* o, relmc_seq_result* res)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_run: relmc_seq_load has not been called");
+    if (!o || !res || o->max_years < 1 || o->batch_years < 0 || (o->years_cap > 0 && o->years_cap < o->max_years && (o->results_year || o->cum_eens || o->cum_cov)))
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_run: bad options (history buffers need room for max_years entries)");
+    std::memset(res, 0, sizeof(*res));
+    const auto t0 = std::chrono::steady_clock::now();
+    const int R = comm_ranks(ctx), r = R > 1 ? ctx->comm_rank : 0;
+    const int64_t batch = o->batch_years > 0 ? o->batch_years : (int64_t)64 * R;
+    std::vector<double> ens, dlc, nlc, trip;
+    std::vector<relmc_seq_year> mine;
+    double kernel_ms = 0.0, mean = 0.0, cov = 0.0;
+    int64_t done = 0; bool stop = false;
+    int64_t n_cont = 0;
+    auto eval = [&](int64_t lo, int64_t cnt, relmc_acc* acc) -> int {      // this rank's years [lo, lo + cnt)
+        relmc_acc_zero(acc);
+        if (cnt <= 0) return RELMC_OK;
+        mine.resize((size_t)cnt);
+        const int rc = relmc_seq_years(ctx, o->seed, (uint64_t)lo, (int32_t)cnt, &o->solver, o->curtail_threshold, mine.data(), acc);
+        if (rc == RELMC_OK) kernel_ms += ctx->last_kernel_ms;
+        return rc;
+    };
+    while (done < o->max_years && !stop) {
+        const int64_t m = (o->max_years - done) < batch ? (o->max_years - done) : batch;
+        const int64_t lo = done + m * r / R, cnt = done + m * (r + 1) / R - lo;
+        relmc_acc acc;
+        int rc = eval(lo, cnt, &acc);
+        const std::string local_err = ctx->err;
+        // annual triples of the batch in year order on every rank; a rank whose years failed says so with NaNs every rank will see
+        trip.assign((size_t)(4 * m), 0.0);
+        for (int64_t k = 0; k < cnt; ++k) {
+            const size_t q = (size_t)(4 * (lo - done + k));
+            if (rc == RELMC_OK) { trip[q] = mine[(size_t)k].ens; trip[q + 1] = mine[(size_t)k].dlc; trip[q + 2] = mine[(size_t)k].nlc; trip[q + 3] = (double)mine[(size_t)k].n_contingency; }
+            else trip[q] = trip[q + 1] = trip[q + 2] = trip[q + 3] = NAN;
+        }
+        if (rc != RELMC_OK && cnt == 0) trip[0] = NAN;
+        if (R > 1) {
+            const int rc2 = comm_allreduce_f64(ctx, trip.data(), 4 * m);
+            if (rc != RELMC_OK) { ctx->err = local_err; return rc; }
+            if (rc2) return rc2;
+            for (double v : trip) if (v != v) return fail(ctx, RELMC_ERR_HIP, "relmc_seq_run: another rank failed to evaluate its years of the batch (see that rank's relmc_last_error)");
+        } else if (rc != RELMC_OK) return rc;
+        int64_t used = m;
+        for (int64_t k = 0; k < m; ++k) {
+            ens.push_back(trip[(size_t)(4 * k)]); dlc.push_back(trip[(size_t)(4 * k + 1)]); nlc.push_back(trip[(size_t)(4 * k + 2)]);
+            const size_t y = ens.size();
+            double s = 0.0; for (double v : ens) s += v;
+            mean = s / (double)y;                                                       // seqMain.m:180
+            cov = 0.0;
+            if (y > 1) {                                                                // :183-185, std = sample standard deviation
+                double ss = 0.0; for (double v : ens) ss += (v - mean) * (v - mean);
+                const double sd = std::sqrt(ss / (double)(y - 1));
+                cov = mean > 0.0 ? sd / (mean * std::sqrt((double)y)) : 0.0;
+            }
+            if (o->results_year) { relmc_seq_year& Y = o->results_year[y - 1]; Y.ens = ens.back(); Y.dlc = dlc.back(); Y.nlc = nlc.back(); Y.n_contingency = (int64_t)trip[(size_t)(4 * k + 3)]; }
+            if (o->cum_eens) o->cum_eens[y - 1] = mean;
+            if (o->cum_cov) o->cum_cov[y - 1] = cov;
+            n_cont += (int64_t)trip[(size_t)(4 * k + 3)];
+            if (y > 1 && cov < o->cov_threshold && cov > 0.0) { stop = true; used = k + 1; break; }      // :194
+        }
+        if (used < m) {
+            // the reference stops inside this batch: its accumulators (seqMain.m:146-159) hold the years up to the stopping year only
+            const int64_t hi = done + used;
+            const int64_t cnt2 = (lo + cnt < hi ? lo + cnt : hi) - lo;
+            rc = eval(lo, cnt2 > 0 ? cnt2 : 0, &acc);
+        }
+        if (R > 1) {
+            const std::string e2 = ctx->err;
+            if (rc != RELMC_OK) { relmc_acc_zero(&acc); acc.n_nonconverged = -((int64_t)1 << 40); }
+            const int rc2 = relmc_comm_allreduce_acc(ctx, &acc);
+            if (rc != RELMC_OK) { ctx->err = e2; return rc; }
+            if (rc2) return rc2;
+            if (acc.n_nonconverged < 0) return fail(ctx, RELMC_ERR_HIP, "relmc_seq_run: another rank failed to re-evaluate its years up to the stopping year");
+        } else if (rc != RELMC_OK) return rc;
+        relmc_acc_merge(&res->acc, &acc);
+        done += used;
+    }
+    const int64_t Y = (int64_t)ens.size();
+    res->final_year = (int32_t)Y; res->converged = stop ? 1 : 0;
+    res->eens = mean; res->cov = cov;
+    double sd = 0.0, sn = 0.0; for (int64_t k = 0; k < Y; ++k) { sd += dlc[(size_t)k]; sn += nlc[(size_t)k]; }
+    res->lole = sd / (double)Y; res->lolf = sn / (double)Y;                             // :212-213
+    res->plc = sd / ((double)Y * (double)ctx->hseq.hpy);
+    res->n_contingency = n_cont;
+    for (int i = 0; i < ctx->nb; ++i) res->nodal_eens_avg[i] = res->acc.sum_nodal[i] / (double)Y;                                        // :218
+    for (int k = 0; k < ctx->ncomp; ++k) res->comp_importance[k] = res->acc.n_fail ? (double)res->acc.comp_fail[k] / (double)res->acc.n_fail : 0.0;   // :233
+    res->kernel_seconds = kernel_ms * 1e-3;
+    res->wall_seconds = std::chrono::duration<double>(std::chrono::steady_clock::now() - t0).count();
+    ctx->last_kernel_ms = kernel_ms;
+    return RELMC_OK;
+}
+
 // ---- HL1 copper sheet: PowerSystemAdequacy.jl:169-208 --------------------------------------------------
 int32_t relmc_hl1_load(relmc_ctx* ctx, int32_t ngen, const double* capacity_mw, const double* for_rate, int32_t nhours,
                        const double* hourly_load_mw)

@@ -88,6 +88,22 @@ class NativeComm:
         self.eng._check(self.eng.L.relmc_comm_allreduce_acc(self.eng._h, C.byref(out)), "relmc_comm_allreduce_acc")
         return out
 
+    def allreduce_f64(self, buf: np.ndarray) -> np.ndarray:
+        """relmc_comm_allreduce_f64: sum over the ranks of a vector of doubles (same result on every rank)."""
+        out = np.ascontiguousarray(buf, dtype=np.float64).copy()
+        self.eng._check(self.eng.L.relmc_comm_allreduce_f64(self.eng._h, out.ctypes.data_as(_abi.c_double_p), int(out.size)), "relmc_comm_allreduce_f64")
+        return out
+
+    def allgather_rows(self, mine: np.ndarray, counts) -> np.ndarray:
+        """Rows of every rank in rank order (ranks may own different numbers of rows): each rank fills its own rows of a zeroed matrix
+        and the matrix is summed over the ranks -- x + 0 + ... + 0 is exact, so this IS an all-gather (what relmc_seq_run does inside)."""
+        mine = np.ascontiguousarray(mine, dtype=np.float64)
+        cols = mine.shape[1]
+        full = np.zeros((int(sum(counts)), cols))
+        lo = int(sum(counts[:self.rank]))
+        full[lo:lo + mine.shape[0]] = mine
+        return self.allreduce_f64(full.ravel()).reshape(-1, cols)
+
     def info(self) -> dict:
         return comm_info(self.eng)
 
@@ -116,6 +132,49 @@ class HostComm(NativeComm):
                 return 1
         self._cb = _abi.ALLREDUCE_FN(_cb)          # kept alive as long as the communicator
         engine._check(engine.L.relmc_comm_set_host_allreduce(engine._h, world, rank, self._cb, None), "relmc_comm_set_host_allreduce")
+
+
+class Watchdog:
+    """Wall-clock guard of one blocking step of the collective path on the Python side (process-group init, the first collective of a
+    transport the library does not own).  `with Watchdog(seconds, what, ...)`: if the block has not finished after `seconds`, the rank says who
+    it is and what it was waiting for on stderr and leaves the process with exit code 86 -- a peer that never arrives turns into a diagnosis,
+    not into the launcher's half-hour timeout.  Never a re-exec: a fresh start is the launcher's business.  seconds <= 0: no guard.
+    (Collectives that go through the library's own communicator are guarded below the C ABI: relmc_comm_set_timeout.)"""
+
+    EXIT_CODE = 86
+
+    def __init__(self, seconds: float, what: str, *, rank: int = 0, world: int = 1, device=None, on_expiry=None):
+        self.seconds, self.what, self.rank, self.world, self.device = float(seconds), what, rank, world, device
+        self._on_expiry = on_expiry
+        self._done = None
+        self._thread = None
+
+    def _run(self):
+        import os
+        import sys
+        if self._done.wait(self.seconds):
+            return
+        print(f"relmc watchdog: rank {self.rank} of {self.world} (pid {os.getpid()}, device {self.device}) has waited {self.seconds:.0f} s in {self.what}: "
+              f"a peer never arrived (wrong rank count, a rank that died or took another path, the rendezvous address, or the fabric).  "
+              f"Leaving with exit code {self.EXIT_CODE}.", file=sys.stderr, flush=True)
+        if self._on_expiry is not None:
+            self._on_expiry()
+        else:
+            os._exit(self.EXIT_CODE)
+
+    def __enter__(self):
+        import threading
+        if self.seconds > 0:
+            self._done = threading.Event()
+            self._thread = threading.Thread(target=self._run, daemon=True)
+            self._thread.start()
+        return self
+
+    def __exit__(self, *exc):
+        if self._thread is not None:
+            self._done.set()
+            self._thread.join()
+        return False
 
 
 def comm_info(engine) -> dict:

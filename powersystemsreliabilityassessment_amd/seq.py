@@ -26,8 +26,7 @@ CURTAIL_THRESHOLD = 0.01     # seqMain.m:41
 MAX_SIM_YEARS = 4000         # seqMain.m:39
 
 
-class SeqYear(C.Structure):
-    _fields_ = [("ens", C.c_double), ("dlc", C.c_double), ("nlc", C.c_double), ("n_contingency", C.c_int64)]
+SeqYear = _abi.SeqYear
 
 
 def seqmeantime() -> np.ndarray:
@@ -51,6 +50,10 @@ def _bind(L):
     L.relmc_seq_mcsimulation.argtypes = [C.c_void_p, u8p, dp, C.c_int64, C.POINTER(_abi.SolverOpts), dp, dp, i32p, i32p]
     L.relmc_seq_years.argtypes = [C.c_void_p, C.c_uint64, C.c_uint64, C.c_int32, C.POINTER(_abi.SolverOpts), C.c_double,
                                   C.POINTER(SeqYear), C.POINTER(_abi.Acc)]
+    L.relmc_seq_opts_default.argtypes = [C.POINTER(_abi.SeqOpts)]
+    L.relmc_seq_opts_default.restype = None
+    L.relmc_seq_run.argtypes = [C.c_void_p, C.POINTER(_abi.SeqOpts), C.POINTER(_abi.SeqResult)]
+    L.relmc_seq_run.restype = C.c_int32
 
 
 class SeqEngine:
@@ -111,65 +114,41 @@ class SeqEngine:
         a = np.array([(y.ens, y.dlc, y.nlc, y.n_contingency) for y in yrs], dtype=np.float64).reshape(-1, 4)
         return a[:, 0], a[:, 1], a[:, 2], a[:, 3].astype(np.int64), acc
 
-    def seqMain_distributed(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD, *, seed: int = 1,
-                            mpopt=None, batch_years: int = 512, device=None) -> dict:
-        """seqMain over the ranks of the default torch.distributed group (one process per GPU): years shard
-        contiguously per super-batch, see dist.seq_run_distributed."""
-        from . import dist as rdist
-
-        def fn(sd, first, n):
-            e, d, n_, _, acc = self.seq_years(sd, first, n, mpopt)
-            return e, d, n_, acc
-        return rdist.seq_run_distributed(fn, seed=seed, cov_threshold=cov_threshold, max_sim_years=max_sim_years,
-                                         batch_years=batch_years, device=device)
-
     # seqMain.m:85-262
     def seqMain(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD,
-                curtail_threshold: float = CURTAIL_THRESHOLD, *, seed: int = 1, mpopt=None, batch_years: int = 64) -> "SeqResult":
-        t0 = time.time()
-        ens, dlc, nlc = [], [], []
-        total = _abi.Acc()
-        eens_hist, cov_hist = [], []
-        from . import dist as rdist
-        done, final_year = 0, 0
-        kernel_ms = 0.0
-        stop = False
-        while done < max_sim_years and not stop:
-            m = min(batch_years, max_sim_years - done)
-            e, d, n_, _, acc = self.seq_years(seed, done, m, mpopt, curtail_threshold)
-            kernel_ms += self.eng.last_kernel_ms()
-            used = m
-            for k in range(m):
-                ens.append(e[k]); dlc.append(d[k]); nlc.append(n_[k])
-                y = len(ens)
-                mean = float(np.mean(ens))                                          # seqMain.m:180
-                eens_hist.append(mean)
-                cov = float(np.std(ens, ddof=1) / (mean * np.sqrt(y))) if y > 1 and mean > 0 else 0.0   # :183-185
-                cov_hist.append(cov)
-                if y > 1 and 0 < cov < cov_threshold:                               # :194
-                    stop, used = True, k + 1
-                    break
-            if used < m:
-                # the reference stops inside this batch: its post-processing accumulators (seqMain.m:146-159)
-                # cover the years up to the stopping year only, so evaluate exactly those again
-                _, _, _, _, acc = self.seq_years(seed, done, used, mpopt, curtail_threshold)
-                kernel_ms += self.eng.last_kernel_ms()
-            total = rdist.merge(total, acc)
-            done += used
-        final_year = len(ens)
-        ens_a, dlc_a, nlc_a = np.array(ens), np.array(dlc), np.array(nlc)
+                curtail_threshold: float = CURTAIL_THRESHOLD, *, seed: int = 1, mpopt=None, batch_years: int = 0) -> "SeqResult":
+        """The yearly loop, its CoV stop and the post-processing run below the C ABI (relmc_seq_run); with a communicator in the engine's
+        context (dist.NativeComm / dist.HostComm) the same call on every rank IS the multi-rank run: the years of every batch shard over the
+        ranks and every rank returns the same result.  batch_years: years per launch round over all ranks (0 = 64 per rank); the result
+        does not depend on it."""
+        o = _abi.SeqOpts()
+        self.L.relmc_seq_opts_default(C.byref(o))
+        o.cov_threshold, o.max_years, o.batch_years = float(cov_threshold), int(max_sim_years), int(batch_years)
+        o.seed, o.curtail_threshold = int(seed), float(curtail_threshold)
+        if mpopt is not None:
+            o.solver = mpopt
+        n = int(max_sim_years)
+        yrs = (SeqYear * n)(); cum_eens = np.zeros(n); cum_cov = np.zeros(n)
+        o.years_cap = n
+        o.results_year = yrs; o.cum_eens = cum_eens.ctypes.data_as(_abi.c_double_p); o.cum_cov = cum_cov.ctypes.data_as(_abi.c_double_p)
+        res = _abi.SeqResult()
+        self.eng._check(self.L.relmc_seq_run(self.eng._h, C.byref(o), C.byref(res)), "relmc_seq_run")
+        y = int(res.final_year)
+        a = np.array([(q.ens, q.dlc, q.nlc) for q in yrs[:y]], dtype=np.float64).reshape(-1, 3)
         nb, nc = self.eng.case.nb, self.eng.case.ncomp
-        loss_hours = int(total.n_fail)
-        years_eval = done
         return SeqResult(
-            final_year=final_year, eens=eens_hist[-1], cov=cov_hist[-1], lole=float(dlc_a.mean()), lolf=float(nlc_a.mean()),
-            results_year=dict(plc=dlc_a / self.hours, nlc=nlc_a, dlc=dlc_a, dns=ens_a / self.hours, ens=ens_a),
-            results_cum=dict(eens=np.array(eens_hist), cov=np.array(cov_hist)),
-            nodal_eens_avg=np.array(total.sum_nodal[:nb]) / years_eval,                                  # :218
-            comp_importance=(np.array(total.comp_fail[:nc], dtype=np.float64) / loss_hours if loss_hours else np.zeros(nc)),   # :233
-            total_loss_hours=loss_hours, years_evaluated=years_eval, n_lp=int(total.n), n_singular=int(total.n_singular),
-            n_infeasible=int(total.n_infeasible), n_nonconverged=int(total.n_nonconverged),
-            elapsed_time=time.time() - t0, kernel_seconds=kernel_ms * 1e-3)
+            final_year=y, eens=res.eens, cov=res.cov, lole=res.lole, lolf=res.lolf,
+            results_year=dict(plc=a[:, 1] / self.hours, nlc=a[:, 2].copy(), dlc=a[:, 1].copy(), dns=a[:, 0] / self.hours, ens=a[:, 0].copy()),
+            results_cum=dict(eens=cum_eens[:y].copy(), cov=cum_cov[:y].copy()),
+            nodal_eens_avg=np.array(res.nodal_eens_avg[:nb]), comp_importance=np.array(res.comp_importance[:nc]),
+            total_loss_hours=int(res.acc.n_fail), years_evaluated=y, n_lp=int(res.acc.n), n_singular=int(res.acc.n_singular),
+            n_infeasible=int(res.acc.n_infeasible), n_nonconverged=int(res.acc.n_nonconverged),
+            elapsed_time=res.wall_seconds, kernel_seconds=res.kernel_seconds, converged=bool(res.converged), acc=res.acc)
+
+    def seqMain_distributed(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD, *, seed: int = 1,
+                            mpopt=None, batch_years: int = 0, device=None) -> "SeqResult":
+        """seqMain over the ranks of the engine's communicator (one process per GPU): the same relmc_seq_run call on every rank."""
+        return self.seqMain(max_sim_years, cov_threshold, seed=seed, mpopt=mpopt, batch_years=batch_years)
 
 
 @dataclass
@@ -191,6 +170,8 @@ class SeqResult:
     n_nonconverged: int
     elapsed_time: float
     kernel_seconds: float
+    converged: bool = True
+    acc: _abi.Acc = field(repr=False, default=None)
 
     def write_nodal_csv(self, path: str) -> None:
         """seq_nodal_results.csv as seqMain.m:255-257."""

@@ -1,5 +1,7 @@
 /* Plain-C client of include/relmc.h: proves the boundary is a C ABI (no C++ types, no Python).
  * Usage: abi_smoke <case.bin>   (case arrays written by tests/test_c_abi.py)  -> prints "n n_fail sum_dns n_distinct" */
+#define _POSIX_C_SOURCE 200809L
+#include <pthread.h>
 #include <stdio.h>
 #include <stdlib.h>
 #include <string.h>
@@ -42,6 +44,81 @@ static int run_two_ranks(const relmc_case_desc* d, const int32_t* order, const r
     return 0;
 }
 
+/* ---- relmc_seq_run (seqMain.m:85-249 below the ABI): alone, with the one-rank RCCL communicator, and as TWO ranks of this process --
+ * two threads, two contexts, and a host collective that is a two-party rendezvous (what an MPI / Julia Distributed host would register). */
+typedef struct { pthread_mutex_t m; pthread_cond_t cv; relmc_acc sum, result[2]; int arrived; unsigned generation; int calls; } pair_t;
+static int32_t pair_allreduce(void* user, relmc_acc* acc)
+{
+    pair_t* p = (pair_t*)user;
+    pthread_mutex_lock(&p->m);
+    const unsigned gen = p->generation;
+    if (p->arrived == 0) p->sum = *acc; else relmc_acc_merge(&p->sum, acc);
+    if (++p->arrived == 2) { p->result[gen & 1u] = p->sum; p->arrived = 0; p->generation++; p->calls++; pthread_cond_broadcast(&p->cv); }
+    else while (gen == p->generation) pthread_cond_wait(&p->cv, &p->m);
+    *acc = p->result[gen & 1u];
+    pthread_mutex_unlock(&p->m);
+    return 0;
+}
+typedef struct { relmc_ctx* ctx; const relmc_seq_opts* o; relmc_seq_result r; relmc_seq_year* years; int rc; } seq_rank_t;
+static void* seq_rank_main(void* arg)
+{
+    seq_rank_t* t = (seq_rank_t*)arg;
+    relmc_seq_opts o = *t->o;
+    o.results_year = t->years;
+    t->rc = relmc_seq_run(t->ctx, &o, &t->r);
+    return NULL;
+}
+static int same_seq(const relmc_seq_result* a, const relmc_seq_result* b, const relmc_seq_year* ya, const relmc_seq_year* yb, int bitwise_sums)
+{
+    if (a->final_year != b->final_year || a->converged != b->converged || a->eens != b->eens || a->cov != b->cov || a->lole != b->lole || a->lolf != b->lolf) return 0;
+    if (memcmp(ya, yb, sizeof(relmc_seq_year) * (size_t)a->final_year) != 0) return 0;                     /* annual indices bit for bit */
+    if (a->acc.n != b->acc.n || a->acc.n_fail != b->acc.n_fail || a->acc.sum_iters != b->acc.sum_iters || a->n_contingency != b->n_contingency) return 0;
+    if (memcmp(a->acc.comp_fail, b->acc.comp_fail, sizeof(a->acc.comp_fail)) != 0 || memcmp(a->comp_importance, b->comp_importance, sizeof(a->comp_importance)) != 0) return 0;
+    for (int i = 0; i < RELMC_MAX_BUS; ++i) {
+        const double x = a->nodal_eens_avg[i], y = b->nodal_eens_avg[i], d = x - y;
+        if (bitwise_sums ? x != y : (d > 1e-9 * (1.0 + x) || d < -1e-9 * (1.0 + x))) return 0;
+    }
+    return 1;
+}
+static int run_seq(relmc_ctx* ctx, const relmc_case_desc* d, const int32_t* order, int hpy, const double* mttf, const double* mttr, const double* lf)
+{
+    enum { MAXY = 600 };
+    if (relmc_seq_load(ctx, mttf, mttr, hpy, lf) != RELMC_OK) return 1;
+    relmc_seq_opts o; relmc_seq_opts_default(&o);
+    if (o.cov_threshold != 0.05 || o.max_years != 4000 || o.curtail_threshold != 0.01) return 2;                /* seqMain.m:39-41 */
+    o.cov_threshold = 0.12; o.max_years = MAXY; o.seed = 3; o.years_cap = MAXY;
+    static relmc_seq_year y_plain[MAXY], y_comm[MAXY], y_r0[MAXY], y_r1[MAXY];
+    relmc_seq_result plain, with_comm;
+    o.results_year = y_plain;
+    if (relmc_seq_run(ctx, &o, &plain) != RELMC_OK) { fprintf(stderr, "seq: %s\n", relmc_last_error(ctx)); return 3; }
+    if (!plain.converged || plain.final_year < 20 || plain.final_year >= MAXY || !(plain.cov > 0 && plain.cov < 0.12) || plain.acc.n_fail <= 0) return 4;
+    /* batch size does not matter, nor does a one-rank RCCL communicator */
+    uint8_t uid[RELMC_COMM_ID_BYTES];
+    if (relmc_comm_unique_id(uid) != RELMC_OK || relmc_comm_init(ctx, 1, 0, uid) != RELMC_OK) return 5;
+    o.results_year = y_comm; o.batch_years = 37;
+    if (relmc_seq_run(ctx, &o, &with_comm) != RELMC_OK) return 6;
+    relmc_comm_destroy(ctx);
+    if (!same_seq(&plain, &with_comm, y_plain, y_comm, 0)) return 7;
+    /* two ranks: two threads, two contexts, a rendezvous as the host's collective; both return the single-rank result */
+    relmc_ctx* c1 = NULL;
+    if (relmc_ctx_create(0, &c1) != RELMC_OK || relmc_case_order_hint(c1, order, d->nb) != RELMC_OK || relmc_case_load(c1, d) != RELMC_OK ||
+        relmc_seq_load(c1, mttf, mttr, hpy, lf) != RELMC_OK) return 8;
+    pair_t pair; memset(&pair, 0, sizeof(pair));
+    pthread_mutex_init(&pair.m, NULL); pthread_cond_init(&pair.cv, NULL);
+    if (relmc_comm_set_host_allreduce(ctx, 2, 0, pair_allreduce, &pair) != RELMC_OK || relmc_comm_set_host_allreduce(c1, 2, 1, pair_allreduce, &pair) != RELMC_OK) return 9;
+    o.batch_years = 0;
+    seq_rank_t t0 = {ctx, &o, plain, y_r0, -1}, t1 = {c1, &o, plain, y_r1, -1};
+    pthread_t th;
+    if (pthread_create(&th, NULL, seq_rank_main, &t1) != 0) return 10;
+    seq_rank_main(&t0);
+    pthread_join(th, NULL);
+    if (t0.rc != RELMC_OK || t1.rc != RELMC_OK) { fprintf(stderr, "seq two ranks: %s | %s\n", relmc_last_error(ctx), relmc_last_error(c1)); return 11; }
+    if (!same_seq(&t0.r, &t1.r, y_r0, y_r1, 1) || !same_seq(&plain, &t0.r, y_plain, y_r0, 0) || pair.calls < 2) return 12;
+    relmc_comm_destroy(ctx); relmc_ctx_destroy(c1);
+    pthread_mutex_destroy(&pair.m); pthread_cond_destroy(&pair.cv);
+    return 0;
+}
+
 int main(int argc, char** argv)
 {
     if (argc < 2) return 2;
@@ -58,6 +135,8 @@ int main(int argc, char** argv)
     d.br_from = rd(f, 4 * d.nl); d.br_to = rd(f, 4 * d.nl); d.br_b = rd(f, 8 * d.nl); d.br_rate = rd(f, 8 * d.nl);
     d.unavail = rd(f, 8 * ncomp); d.always_up = rd(f, ncomp);
     int32_t* order = rd(f, 4 * d.nb);                 /* primary elimination order of the solver schedule (the package's tuned order) */
+    int32_t* hpy = rd(f, 4);                          /* sequential track: hours per year, [MTTF MTTR] (seqmeantime.m), hourly load factors (anloducurve.m) */
+    double* mttf = rd(f, 8 * ncomp); double* mttr = rd(f, 8 * ncomp); double* lf = rd(f, 8 * (size_t)hpy[0]);
     fclose(f);
     relmc_ctx* ctx = NULL;
     if (relmc_ctx_create(0, &ctx) != RELMC_OK) { fprintf(stderr, "no device\n"); return 3; }
@@ -103,6 +182,7 @@ int main(int argc, char** argv)
     /* the multi-rank loop itself (relmc_nsq_run with R > 1: contiguous split of every batch, one all-reduce per batch) on this one GPU:
      * a host collective for "2 ranks" whose transport is this process evaluating the OTHER rank's slice on a second context */
     if (run_two_ranks(&d, order, &no, &r_plain) != 0) return 21;
+    { const int rs = run_seq(ctx, &d, order, hpy[0], mttf, mttr, lf); if (rs != 0) { fprintf(stderr, "relmc_seq_run check %d failed\n", rs); return 24; } }
     printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
     relmc_ctx_destroy(ctx);
     return 0;

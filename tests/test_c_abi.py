@@ -17,7 +17,7 @@ def _build_client(tmp_path):
         _lib.build()                              # hipcc cross-compiles without a GPU
     exe = str(tmp_path / "abi_smoke")
     subprocess.check_call(["gcc", "-std=c11", "-Wall", "-Wextra", "-Werror", "-I", INC, os.path.join(ROOT, "tests", "c", "abi_smoke.c"),
-                           "-o", exe, "-L", CSRC, "-lrelmc", "-Wl,-rpath," + CSRC])
+                           "-o", exe, "-pthread", "-L", CSRC, "-lrelmc", "-Wl,-rpath," + CSRC])
     return exe
 
 
@@ -41,6 +41,10 @@ def test_plain_c_client(tmp_path, case):
                      (case.br_rate, np.float64), (case.unavail, np.float64), (case.always_up, np.uint8)):
             fh.write(np.ascontiguousarray(a, dtype=t).tobytes())
         fh.write(np.ascontiguousarray(case.elim_order, dtype=np.int32).tobytes())      # relmc_case_order_hint: the engine below loads it too
+        from powersystemsreliabilityassessment_amd import loadcurve, seq
+        rel = seq.seqmeantime(); lf = loadcurve.anloducurve(8736)[2]                    # relmc_seq_load's arguments (the client runs relmc_seq_run)
+        fh.write(np.array([8736], dtype=np.int32).tobytes())
+        fh.write(np.ascontiguousarray(rel[:, 0]).tobytes()); fh.write(np.ascontiguousarray(rel[:, 1]).tobytes()); fh.write(np.ascontiguousarray(lf, dtype=np.float64).tobytes())
     out = None
     for attempt in range(2):                      # the client takes ~7 s; one run in ~15 on the GPU pool stalled inside RCCL's one-rank bootstrap
         try:
@@ -69,13 +73,13 @@ def test_struct_layouts_match_the_mirrors(tmp_path):
     block = jl[jl.index("const LAYOUT = ["):]
     block = block[:block.index("\n]\n") + 3]
     consts = dict(MAX_COMP=256, MAX_BUS=128)
-    for m in re.finditer(r'^const (NSQ_RESULT_\w+) = (.+?)(?:#.*)?$', jl, re.M):        # derived offsets of relmc_nsq_result
+    for m in re.finditer(r'^const ((?:NSQ|SEQ)_RESULT_\w+) = (.+?)(?:#.*)?$', jl, re.M):        # derived offsets of relmc_nsq_result / relmc_seq_result
         consts[m.group(1)] = int(eval(m.group(2), {}, consts))
     table = []
     for m in re.finditer(r'\("(relmc_\w+)",\s*([^,\[]+),\s*\[(.*?)\]\)', block):
         fields = [(f, int(eval(off, {}, consts))) for f, off in re.findall(r'\("(\w+)",\s*([^)]+)\)', m.group(3))]
         table.append((m.group(1), int(eval(m.group(2), {}, consts)), fields))
-    assert len(table) == 9
+    assert len(table) == 11
     prog = ['#include <stdio.h>', '#include <stddef.h>', '#include "relmc.h"', 'int main(void) {']
     for name, _, fields in table:
         prog.append(f'printf("{name} %zu", sizeof({name}));')
@@ -93,7 +97,7 @@ def test_struct_layouts_match_the_mirrors(tmp_path):
     for name, size, fields in table:
         assert got[name] == [size] + [off for _, off in fields], name
     mirror = {"relmc_case_desc": _abi.CaseDesc, "relmc_solver_opts": _abi.SolverOpts, "relmc_acc": _abi.Acc, "relmc_indices": _abi.Indices,
-              "relmc_db_stats": _abi.DbStats}
+              "relmc_db_stats": _abi.DbStats, "relmc_seq_opts": _abi.SeqOpts, "relmc_seq_result": _abi.SeqResult, "relmc_seq_year": _abi.SeqYear}
     for name, size, fields in table:
         if name in mirror:
             assert C.sizeof(mirror[name]) == size, name
@@ -101,3 +105,31 @@ def test_struct_layouts_match_the_mirrors(tmp_path):
                 assert getattr(mirror[name], f).offset == off, (name, f)
     assert got["py_nsq_opts"] == [C.sizeof(_abi.NsqOpts), _abi.NsqOpts.solver.offset, _abi.NsqOpts.distinct_states.offset]
     assert got["py_nsq_result"] == [C.sizeof(_abi.NsqResult), _abi.NsqResult.checkpoints.offset, _abi.NsqResult.batches.offset]
+
+
+_GUARD_SCRIPT = r"""
+import sys, time
+sys.path.insert(0, {root!r})
+import ctypes as C
+from powersystemsreliabilityassessment_amd import _abi, api, case24
+eng = api.Engine(case24.rts24())
+eng.comm_set_timeout(1.0)
+cb = _abi.ALLREDUCE_FN(lambda user, acc: (time.sleep(30), 0)[1])          # the peer that never arrives
+eng._check(eng.L.relmc_comm_set_host_allreduce(eng._h, 2, 0, cb, None), "relmc_comm_set_host_allreduce")
+acc = eng.nsq_accumulate(1, 0, 1000)
+eng.L.relmc_comm_allreduce_acc(eng._h, C.byref(acc))
+print("collective returned", flush=True)
+"""
+
+
+@pytest.mark.gpu
+def test_library_guard_ends_a_hung_collective_with_a_diagnosis(tmp_path):
+    """relmc_comm_set_timeout: a collective through the context that does not come back within the limit (here a host callback that sleeps)
+    ends the process with exit code 86 and a line saying which rank, which GPU (PCI bus id) and what it was waiting for."""
+    import sys
+    script = tmp_path / "guard.py"
+    script.write_text(_GUARD_SCRIPT.format(root=ROOT))
+    out = subprocess.run([sys.executable, str(script)], capture_output=True, text=True, timeout=240)
+    assert out.returncode == 86, (out.returncode, out.stderr[-800:])
+    assert "rank 0 of 2" in out.stderr and "has waited 1 s in the host's all-reduce callback (relmc_acc)" in out.stderr and "PCI 0000:" in out.stderr
+    assert "collective returned" not in out.stdout

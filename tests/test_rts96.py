@@ -274,6 +274,33 @@ def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
 
 
 @pytest.mark.gpu
+def test_gpu_second_larger_case_on_one_context_resizes_the_retry_scratch(case96_, oracle96, numfail96):
+    """One context, two cases: RTS-24 first, with retries forced (an iteration limit of 7 lists nearly every unit), then RTS-96
+    on the SAME engine and the numfail fixture through mc_simulation, whose 51 states all go to the further orders.  The scratch rows of the
+    re-evaluation are sized with the loaded case's bus count (24, then 73): the second case's retries must not write past the first's."""
+    from powersystemsreliabilityassessment_amd import api
+    eng = api.Engine(case24.rts24())
+    o = api.mpoption(); o.max_it = 7
+    acc = eng.nsq_accumulate(1, 0, 20000, o)
+    assert eng.retry_stats()[0] > 4000 and acc.n == 20000
+    eng.load_case(case96_)
+    assert eng.retry_stats() == (0, 0)
+    N = len(numfail96["states"])
+    big = np.tile(numfail96["matrix"], (100, 1))                  # 5 100 listed units: more rows than the first case's scratch held
+    dns, nodal, info = eng.mc_simulation(big, return_info=True)
+    assert eng.retry_stats()[0] == 100 * N
+    r = oracle96.mc_simulation(numfail96["matrix"], _abi.RELMC_REFERENCE_EMULATE, nthreads=16)
+    np.testing.assert_allclose(dns.reshape(100, N), np.tile(r["dns"], (100, 1)), rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(nodal.reshape(100, N, -1), np.tile(nodal[:N], (100, 1, 1)))
+    np.testing.assert_allclose(nodal[:N].sum(1)[dns[:N] > 0], dns[:N][dns[:N] > 0], rtol=0, atol=5e-3)
+    assert (info["status"][:N] == 0).sum() >= N - 1
+    # and back to the small case
+    eng.load_case(case24.rts24())
+    assert eng.nsq_accumulate(1, 0, 20000).n_nonconverged == 0
+    eng.close()
+
+
+@pytest.mark.gpu
 def test_gpu96_dense_last_resort_on_the_numfail_states(engine96, oracle96, numfail96):
     """The 51 RTS-96 states the primary static order ends 'numerically failed' on, through the dense partially pivoted solve alone (the
     third retry level, reached by 2 units in 1e9 samples once the further static orders have had their turn): it converges on at least as

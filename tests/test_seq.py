@@ -253,6 +253,34 @@ def test_gpu_seqmain_vs_golden(seqeng, seq_golden, tmp_path):
 
 
 @pytest.mark.gpu
+def test_gpu_seq_run_below_the_abi_equals_the_python_loop(seqeng):
+    """relmc_seq_run (the seqMain loop, its CoV stop and post-processing below the C ABI) against the Python restatement of the same loop
+    around relmc_seq_years (dist.seq_run_distributed, the loop the gloo test checks the sharding arithmetic of): same stopping year, annual
+    indices bit for bit, CoV curve to rounding, accumulators cut at the stopping year, whatever the batch size."""
+    from powersystemsreliabilityassessment_amd import dist as rdist
+
+    def fn(sd, first, n):
+        e, d, n_, _, acc = seqeng.seq_years(sd, first, n)
+        return e, d, n_, acc
+    ref = rdist.seq_run_distributed(fn, seed=5, cov_threshold=0.08, max_sim_years=2000, batch_years=100, rank=0, world=1)
+    for by in (0, 33, 700):
+        r = seqeng.seqMain(2000, 0.08, seed=5, batch_years=by)
+        assert r.converged and r.final_year == ref["final_year"] and 50 < r.final_year < 2000
+        np.testing.assert_array_equal(np.column_stack([r.results_year["ens"], r.results_year["dlc"], r.results_year["nlc"]]), ref["years"])
+        np.testing.assert_allclose(r.results_cum["cov"][1:], ref["cum_cov"][1:], rtol=1e-12)
+        np.testing.assert_allclose(r.results_cum["eens"], ref["cum_eens"], rtol=1e-13)
+        assert r.results_cum["cov"][0] == 0.0 and r.cov == r.results_cum["cov"][-1] < 0.08 <= r.results_cum["cov"][-2]
+        ai, ad = r.acc.to_arrays(); bi, bd = ref["acc"].to_arrays()
+        np.testing.assert_array_equal(ai, bi)
+        np.testing.assert_allclose(ad, bd, rtol=1e-12, atol=1e-9)
+        assert r.total_loss_hours == int(r.results_year["dlc"].sum()) and r.lole == pytest.approx(ref["lole"]) and r.lolf == pytest.approx(ref["lolf"])
+        np.testing.assert_allclose(r.nodal_eens_avg, np.array(ref["acc"].sum_nodal[:24]) / r.final_year, rtol=1e-12)
+    # no convergence within the horizon: every year kept, converged = False
+    r = seqeng.seqMain(40, 1e-6, seed=5)
+    assert not r.converged and r.final_year == 40 and r.years_evaluated == 40
+
+
+@pytest.mark.gpu
 def test_gpu_long_run_tightens_on_golden(seqeng, seq_golden):
     """20 000 simulated years (about 1.4e8 hourly OPFs): the golden means sit within the golden run's own error."""
     ens, dlc, nlc = [], [], []
