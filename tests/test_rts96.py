@@ -286,12 +286,13 @@ def test_gpu_second_larger_case_on_one_context_resizes_the_retry_scratch(case96_
     eng.load_case(case96_)
     assert eng.retry_stats() == (0, 0)
     N = len(numfail96["states"])
-    big = np.tile(numfail96["matrix"], (100, 1))                  # 5 100 listed units: more rows than the first case's scratch held
+    R = 80                                                          # 4 080 listed units: the list of a per-state call holds 4096 + n / 256
+    big = np.tile(numfail96["matrix"], (R, 1))
     dns, nodal, info = eng.mc_simulation(big, return_info=True)
-    assert eng.retry_stats()[0] == 100 * N
+    assert eng.retry_stats()[0] == R * N and eng.retry_overflow() == 0
     r = oracle96.mc_simulation(numfail96["matrix"], _abi.RELMC_REFERENCE_EMULATE, nthreads=16)
-    np.testing.assert_allclose(dns.reshape(100, N), np.tile(r["dns"], (100, 1)), rtol=0, atol=1e-5)
-    np.testing.assert_array_equal(nodal.reshape(100, N, -1), np.tile(nodal[:N], (100, 1, 1)))
+    np.testing.assert_allclose(dns.reshape(R, N), np.tile(r["dns"], (R, 1)), rtol=0, atol=1e-5)
+    np.testing.assert_array_equal(nodal.reshape(R, N, -1), np.tile(nodal[:N], (R, 1, 1)))
     np.testing.assert_allclose(nodal[:N].sum(1)[dns[:N] > 0], dns[:N][dns[:N] > 0], rtol=0, atol=5e-3)
     assert (info["status"][:N] == 0).sum() >= N - 1
     # and back to the small case
