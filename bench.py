@@ -80,6 +80,7 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # ONE node: RCCL's bootstrap sockets over loopback (the container's hostname may not resolve); xGMI carries the data
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_device:
