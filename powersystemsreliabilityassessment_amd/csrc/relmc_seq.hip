@@ -200,8 +200,9 @@ int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* o, relmc_seq_result*
 {
     if (!ctx) return RELMC_ERR_INVALID;
     if (!ctx->has_seq) return fail(ctx, RELMC_ERR_NO_CASE, "relmc_seq_run: relmc_seq_load has not been called");
-    if (!o || !res || o->max_years < 1 || o->batch_years < 0 || (o->years_cap > 0 && o->years_cap < o->max_years && (o->results_year || o->cum_eens || o->cum_cov)))
-        return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_run: bad options (history buffers need room for max_years entries)");
+    if (!o || !res || o->max_years < 1 || o->batch_years < 0 || !(o->cov_threshold >= 0.0) ||
+        ((o->results_year || o->cum_eens || o->cum_cov) && o->years_cap < o->max_years))
+        return fail(ctx, RELMC_ERR_INVALID, "relmc_seq_run: bad options (max_years >= 1, batch_years >= 0; history buffers need years_cap >= max_years entries)");
     std::memset(res, 0, sizeof(*res));
     const auto t0 = std::chrono::steady_clock::now();
     const int R = comm_ranks(ctx), r = R > 1 ? ctx->comm_rank : 0;

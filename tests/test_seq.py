@@ -275,9 +275,18 @@ def test_gpu_seq_run_below_the_abi_equals_the_python_loop(seqeng):
         np.testing.assert_allclose(ad, bd, rtol=1e-12, atol=1e-9)
         assert r.total_loss_hours == int(r.results_year["dlc"].sum()) and r.lole == pytest.approx(ref["lole"]) and r.lolf == pytest.approx(ref["lolf"])
         np.testing.assert_allclose(r.nodal_eens_avg, np.array(ref["acc"].sum_nodal[:24]) / r.final_year, rtol=1e-12)
-    # no convergence within the horizon: every year kept, converged = False
+    # no convergence within the horizon: every year kept, converged = False; a horizon of one year; options the library refuses
     r = seqeng.seqMain(40, 1e-6, seed=5)
     assert not r.converged and r.final_year == 40 and r.years_evaluated == 40
+    r1 = seqeng.seqMain(1, 0.05, seed=5)
+    assert r1.final_year == 1 and not r1.converged and r1.cov == 0.0 and r1.results_year["ens"][0] == r.results_year["ens"][0]
+    import ctypes as C
+    o = _abi.SeqOpts(); seqeng.L.relmc_seq_opts_default(C.byref(o)); res = _abi.SeqResult()
+    buf = np.zeros(10)
+    o.max_years = 100; o.years_cap = 10; o.cum_eens = buf.ctypes.data_as(_abi.c_double_p)          # history buffer shorter than the horizon
+    assert seqeng.L.relmc_seq_run(seqeng.eng._h, C.byref(o), C.byref(res)) == -1 and b"years_cap" in seqeng.L.relmc_last_error(seqeng.eng._h)
+    o.cum_eens = None; o.max_years = 0
+    assert seqeng.L.relmc_seq_run(seqeng.eng._h, C.byref(o), C.byref(res)) == -1
 
 
 @pytest.mark.gpu
