@@ -11,6 +11,9 @@
 #include <new>
 
 #include "relmc_ctx.h"
+#ifdef RELMC_DEV_SWITCHES
+#include "relmc_dev_switches.h"
+#endif
 #include "relmc_kernels.hip"
 
 static_assert(sizeof(relmc::DevAcc) == sizeof(relmc_acc), "device accumulator image must match relmc_acc");
@@ -278,7 +281,7 @@ using namespace relmc_host;
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.7 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules with a tunable elimination order + dense pivoted last resort, device state database, multi-rank loop)"; }
+const char* relmc_version(void) { return "relmc 0.8 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules with a tunable elimination order + dense pivoted last resort, device state database, nsqMain and seqMain loops below the ABI, guarded collectives)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
@@ -303,8 +306,7 @@ int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
     ctx->num_cu = prop.multiProcessorCount;
     ctx->blocks_per_cu = 1;
 #ifdef RELMC_DEV_SWITCHES      // diagnosis builds only (csrc/Makefile: ablate/librelmc_dev.so); the default build has relmc_debug_set alone
-    ctx->sw.no_retry = std::getenv("RELMC_NO_RETRY") != nullptr; ctx->sw.retry_dense_first = std::getenv("RELMC_RETRY_DENSE_FIRST") != nullptr;
-    ctx->sw.nsq_no_stretch = std::getenv("RELMC_NSQ_NO_STRETCH") != nullptr; ctx->sw.db_no_probe = std::getenv("RELMC_DB_NO_PROBE") != nullptr;
+    relmc_dev_switches_context(ctx->sw);
 #endif
     *out = ctx;
     return RELMC_OK;

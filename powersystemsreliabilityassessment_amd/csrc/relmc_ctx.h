@@ -107,6 +107,7 @@ struct relmc_ctx {
     bool has_seq = false; relmc::SeqCase hseq; relmc::SeqCase* dseq = nullptr; double* dlf = nullptr;
     // HL1 copper-sheet model
     bool has_hl1 = false; relmc::Hl1Case* dhl1 = nullptr; double* dsorted = nullptr; double* dsuffix = nullptr; int hl1_hours = 0;
+    double* h1_lole = nullptr; double* h1_eue = nullptr; int64_t h1_cap = 0; double* h1_part = nullptr; int64_t h1_part_cap = 0;   // relmc_hl1_nsq's device buffers, grow-only
     double last_kernel_ms = 0.0;
     long conflict_before = 0, conflict_after = 0;   // modelled extra LDS cycles per Newton step before / after the placement search
     long alt_conflict_before[kAlt] = {0, 0}, alt_conflict_after[kAlt] = {0, 0};      // the same of the further orders' images

@@ -11,6 +11,9 @@
 #include <memory>
 
 #include "relmc_ctx.h"
+#ifdef RELMC_DEV_SWITCHES
+#include "relmc_dev_switches.h"
+#endif
 
 namespace relmc_host {
 
@@ -24,10 +27,7 @@ SymOpts sym_opts_default()
 {
     SymOpts so;
 #ifdef RELMC_DEV_SWITCHES      // ablation builds (csrc/Makefile: ablate/librelmc_dev.so): schedule forms and search weights from the environment
-    if (const char* q = std::getenv("RELMC_PLACE_WW")) so.place_ww = std::atol(q);
-    if (const char* q = std::getenv("RELMC_PLACE_MOVES")) so.place_moves = std::atoi(q);
-    so.no_quarter = std::getenv("RELMC_NO_QUARTER") != nullptr; so.no_half = std::getenv("RELMC_NO_HALF") != nullptr;
-    so.no_bwd_half = std::getenv("RELMC_NO_BWD_HALF") != nullptr; so.no_bus_map = std::getenv("RELMC_NO_BUS_MAP") != nullptr;
+    relmc_dev_switches_schedule(so);
 #endif
     return so;
 }

@@ -13,7 +13,8 @@ namespace relmc_host {
 void seq_free(relmc_ctx* ctx)
 {
     for (void* q : {(void*)ctx->sq_dm, (void*)ctx->sq_hours, (void*)ctx->sq_curt, (void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year, (void*)ctx->dseq,
-                    (void*)ctx->dlf, (void*)ctx->dhl1, (void*)ctx->dsorted, (void*)ctx->dsuffix}) if (q) (void)hipFree(q);
+                    (void*)ctx->dlf, (void*)ctx->dhl1, (void*)ctx->dsorted, (void*)ctx->dsuffix, (void*)ctx->h1_lole, (void*)ctx->h1_eue, (void*)ctx->h1_part}) if (q) (void)hipFree(q);
+    ctx->h1_lole = ctx->h1_eue = ctx->h1_part = nullptr; ctx->h1_cap = 0; ctx->h1_part_cap = 0;
     ctx->sq_dm = nullptr; ctx->sq_hours = nullptr; ctx->sq_curt = nullptr; ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr;
     ctx->sq_dm_words = 0; ctx->sq_nh = 0; ctx->sq_years = 0;
     ctx->dseq = nullptr; ctx->dlf = nullptr; ctx->dhl1 = nullptr; ctx->dsorted = ctx->dsuffix = nullptr; ctx->has_seq = false; ctx->has_hl1 = false;
@@ -333,21 +334,33 @@ int32_t relmc_hl1_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     int64_t blocks = (n + 255) / 256;
     if (blocks > (int64_t)ctx->num_cu * 8) blocks = (int64_t)ctx->num_cu * 8;
-    double *dl = nullptr, *de = nullptr, *dpart = nullptr;
+    // per-iteration outputs and block partials live in the context between calls (three hipMalloc / hipFree pairs were 0.5 ms of a 0.8 ms call)
+    if ((iter_lole_host || iter_eue_host) && n > ctx->h1_cap) {
+        if (ctx->h1_lole) (void)hipFree(ctx->h1_lole);
+        if (ctx->h1_eue) (void)hipFree(ctx->h1_eue);
+        ctx->h1_lole = ctx->h1_eue = nullptr; ctx->h1_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->h1_lole, sizeof(double) * (size_t)n));
+        HIP_TRY(ctx, hipMalloc(&ctx->h1_eue, sizeof(double) * (size_t)n));
+        ctx->h1_cap = n;
+    }
+    if (blocks > ctx->h1_part_cap) {
+        if (ctx->h1_part) (void)hipFree(ctx->h1_part);
+        ctx->h1_part = nullptr; ctx->h1_part_cap = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->h1_part, sizeof(double) * 4 * (size_t)blocks));
+        ctx->h1_part_cap = blocks;
+    }
+    double* const dl = iter_lole_host ? ctx->h1_lole : nullptr; double* const de = iter_eue_host ? ctx->h1_eue : nullptr; double* const dpart = ctx->h1_part;
     int rc = RELMC_OK;
-    auto cleanup = [&]() { (void)hipFree(dl); (void)hipFree(de); (void)hipFree(dpart); };
-    if ((iter_lole_host && hipMalloc(&dl, sizeof(double) * n) != hipSuccess) || (iter_eue_host && hipMalloc(&de, sizeof(double) * n) != hipSuccess) ||
-        hipMalloc(&dpart, sizeof(double) * 4 * blocks) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: device allocation failed"); }
     (void)hipEventRecord(ctx->ev0, ctx->stream);
     hipLaunchKernelGGL(relmc_hl1_kernel, dim3((unsigned)blocks), dim3(256), 0, ctx->stream, ctx->dhl1, ctx->dsorted, ctx->dsuffix, seed,
                        first_index, n, dl, de, dpart);
     (void)hipEventRecord(ctx->ev1, ctx->stream);
     std::vector<double> part((size_t)4 * blocks);
-    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, sizeof(double) * 4 * blocks, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
-        finish_timing(ctx) != RELMC_OK) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: launch failed");
-    if (rc == RELMC_OK && iter_lole_host && hipMemcpy(iter_lole_host, dl, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
-    if (rc == RELMC_OK && iter_eue_host && hipMemcpy(iter_eue_host, de, sizeof(double) * n, hipMemcpyDeviceToHost) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
-    cleanup();
+    if (hipGetLastError() != hipSuccess || hipMemcpyAsync(part.data(), dpart, sizeof(double) * 4 * blocks, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)
+        rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: launch failed");
+    if (rc == RELMC_OK && iter_lole_host && hipMemcpyAsync(iter_lole_host, dl, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    if (rc == RELMC_OK && iter_eue_host && hipMemcpyAsync(iter_eue_host, de, sizeof(double) * n, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: D2H failed");
+    if (rc == RELMC_OK && finish_timing(ctx) != RELMC_OK) rc = fail(ctx, RELMC_ERR_HIP, "relmc_hl1_nsq: synchronisation failed");
     if (rc) return rc;
     acc->n = n;
     for (int64_t b = 0; b < blocks; ++b) { acc->sum_lole += part[4 * b]; acc->sum_eue += part[4 * b + 1]; acc->sum_lole2 += part[4 * b + 2]; acc->sum_eue2 += part[4 * b + 3]; }
