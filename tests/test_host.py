@@ -292,6 +292,12 @@ def test_bench_comm_paths_are_self_evidencing(tmp_path):
     np.testing.assert_allclose([float.fromhex(x) for x in a2["dbls"]], [float.fromhex(x) for x in a1["dbls"]], rtol=1e-11, atol=1e-9)
     ttc = j2["time_to_cov_1pct"]
     assert "relmc_nsq_run" in ttc["loop"] and ttc["beta"] < 0.01 and ttc["samples"] % 200000 == 0
+    # the sequential workload over two ranks: the annual indices travel through the library's communicator (relmc_comm_allreduce_f64 over the
+    # registered host collective), the accumulators of 2 x 8 years per step equal one rank's 16
+    q2, c2 = run(2, ["--workload", "seq", "--years", "8", "--comm", "host", "--no-time-to-cov"], "q2")
+    q1, c1 = run(1, ["--workload", "seq", "--years", "16", "--no-time-to-cov"], "q1")
+    assert q2["unit"] == "hourly DC-OPFs/s" and q2["comm"]["nranks_seen"] == 2 and q2["indices"]["n"] == q1["indices"]["n"] > 0 and c2["ints"] == c1["ints"]
+    np.testing.assert_allclose([float.fromhex(x) for x in c2["dbls"]], [float.fromhex(x) for x in c1["dbls"]], rtol=1e-11, atol=1e-9)
     bad = run(2, ["--batch", "20000", "--no-time-to-cov"], "x2", expect_ok=False)          # --comm native is the default for N > 1
     assert bad.returncode != 0
     assert bad.stderr.count("communicator init failed") >= 1 and "ncclCommInitRank" in bad.stderr, bad.stderr[-1500:]
