@@ -33,6 +33,19 @@ def fixture96(case96_):
     return d
 
 
+def _three_area_states(case96_, area_states):
+    """RTS-96 states made of three RTS-24 states (one per area) with the five tie lines out: three electrically separate RTS-24 systems
+    (bus 325 hangs on 323 through its transformer, which stays in service: a dead end without load or generation)."""
+    k = area_states.shape[0] // 3
+    st = np.zeros((k, case96_.ncomp), dtype=np.uint8)
+    for a in range(3):
+        part = area_states[a * k:(a + 1) * k]
+        st[:, 33 * a:33 * (a + 1)] = part[:, :33]
+        st[:, 99 + 38 * a:99 + 38 * (a + 1)] = part[:, 33:]
+    st[:, 99 + 114:99 + 119] = 1
+    return st
+
+
 # ---------------------------------------------------------------------------------------------- CPU
 def test_case96_construction(case96_):
     c = case96_
@@ -55,6 +68,28 @@ def test_case96_construction(case96_):
     np.testing.assert_allclose(u, [0.44 / (0.44 + 876), 0.47 / (0.47 + 8760 / 11), 0.46 / (0.46 + 8760 / 11), 0.52 / (0.52 + 8760 / 11),
                                    0.54 / (0.54 + 8760 / 11), 0.02 / (0.02 + 8760 / 768)], rtol=1e-12)
     assert case96.seqmeantime96().shape == (219, 2)
+
+
+def test_oracle96_with_the_ties_out_is_three_rts24_systems(oracle96, oracle, case96_):
+    """A pin of the RTS-96 case (recalled, not validated by the reference) that does not depend on the recalled part: with
+    the five tie lines out the 73-bus LP decouples into three RTS-24 LPs, so its curtailment must be the sum of what the RTS-24 case -- the one
+    the reference's goldens pin -- gives for the three area states (the LP optimum is unique), area by area in the nodal sums too.  Checks the
+    replication of the area data, the bus / branch / generator numbering and the island rules (areas 2 and 3 have no reference bus)."""
+    rng = np.random.default_rng(96)
+    k = 16
+    areas = (rng.random((3 * k, 71)) < 0.09).astype(np.uint8)       # heavy outages: most areas shed load
+    areas[:, 14] = 0
+    st = _three_area_states(case96_, areas)
+    for pol in (_abi.RELMC_PHYSICAL,):
+        r96 = oracle96.mc_simulation(st, pol, nthreads=8)
+        r24 = oracle.mc_simulation(areas, pol, nthreads=8)
+        want = r24["dns"][:k] + r24["dns"][k:2 * k] + r24["dns"][2 * k:]
+        ok = np.all(np.isin(r96["status"], (0,))) and np.all(r24["status"] == 0)
+        assert ok and (want > 1.0).sum() >= k // 2
+        np.testing.assert_allclose(r96["dns"], want, rtol=0, atol=2e-5)
+        for a in range(3):
+            np.testing.assert_allclose(r96["nodal"][:, 24 * a:24 * (a + 1)].sum(1), r24["nodal"][a * k:(a + 1) * k].sum(1), rtol=0, atol=2e-2)
+        assert np.all(r96["nodal"][:, 72] == 0)
 
 
 def test_oracle96_vs_fixture(oracle96, fixture96):
@@ -130,6 +165,39 @@ def test_gpu96_accumulate_matches_oracle(engine96, oracle96):
     assert ad[2:].sum() == pytest.approx(rd[2:].sum(), rel=1e-6)
     np.testing.assert_allclose(ad[2:], rd[2:], rtol=2e-2, atol=1.0)
     assert acc.n == n and acc.n_nonconverged == 0
+
+
+@pytest.mark.gpu
+def test_gpu96_with_the_ties_out_is_three_rts24_systems(engine96, engine, case96_):
+    """The same decoupling on the device, on sampled area states at two outage levels: the 64-lane tile's curtailment of a three-island RTS-96
+    state equals the sum of the 16-lane tile's on the three RTS-24 area states (1e-5 MW), per area in the nodal sums, under both policies
+    wherever no bus is isolated (multi-bus islands without the reference bus are solved island-aware in both)."""
+    from powersystemsreliabilityassessment_amd import api
+    rng = np.random.default_rng(97)
+    k = 400
+    sampled = engine.mc_sampling(None, 3 * k, seed=96, first_index=0)
+    heavy = (rng.random((3 * k, 71)) < 0.08).astype(np.uint8); heavy[:, 14] = 0
+    # bus 323 keeps the transformer to 325 when all its RTS-24 lines are out (a two-bus island, not an isolated bus): keep one of them in service
+    l23 = 33 + int(np.flatnonzero((case24.BR_FROM == 23) | (case24.BR_TO == 23))[0])
+    sampled[2 * k:, l23] = 0; heavy[2 * k:, l23] = 0
+    for areas in (sampled, heavy):
+        st = _three_area_states(case96_, areas)
+        for pol in (api.PHYSICAL, api.REFERENCE_EMULATE):
+            d96, n96, i96 = engine96.mc_simulation(st, mpopt=api.mpoption(pol), return_info=True)
+            d24, n24, i24 = engine.mc_simulation(areas, mpopt=api.mpoption(pol), return_info=True)
+            sing24 = (i24["status"] == 3).reshape(3, k).any(0)                 # an isolated bus in some area: the emulated singular case
+            assert np.array_equal(i96["status"] == 3, sing24), (np.flatnonzero((i96["status"] == 3) != sing24)[:5], np.unique(i96["status"]), np.unique(i24["status"]))
+            conv = (i96["status"] == 0) & (i24["status"] == 0).reshape(3, k).all(0)      # heavy-outage states may end non-converged on either tile (6.7e-7 of the sampled ones)
+            assert conv.sum() >= (~sing24).sum() - 2
+            want = d24[:k] + d24[k:2 * k] + d24[2 * k:]
+            part = d24.reshape(3, k)
+            clean = conv & ~sing24 & ~(((part > 0) & (part < 0.2)).any(0)) & ~((want > 0) & (want < 0.2))      # away from the 0.1 MW noise filter
+            assert clean.sum() > 0.9 * k or pol == api.REFERENCE_EMULATE
+            np.testing.assert_allclose(d96[clean], want[clean], rtol=0, atol=1e-5)
+            for a in range(3):
+                np.testing.assert_allclose(n96[clean][:, 24 * a:24 * (a + 1)].sum(1), n24[a * k:(a + 1) * k][clean].sum(1), rtol=0, atol=2e-2)
+            assert np.all(n96[:, 72] == 0)
+        assert (want > 1.0).sum() > (20 if areas is sampled else k // 2)
 
 
 @pytest.mark.gpu
