@@ -173,6 +173,45 @@ class SeqResult:
     converged: bool = True
     acc: _abi.Acc = field(repr=False, default=None)
 
+    # -- what seqMain prints (seqMain.m:187-197, 206-249) ---------------------------------------------------------
+    def progress_lines(self, every: int = 10) -> list[str]:
+        """The loop's progress print (seqMain.m:187-190: every 10th year from the second on) and the convergence line (:195)."""
+        out = []
+        for y in range(2, self.final_year + 1):
+            if y % every == 0:
+                out.append("Year %4d | EENS: %.4f MWh/yr | CoV: %.4f" % (y, self.results_cum["eens"][y - 1], self.results_cum["cov"][y - 1]))
+        if self.converged:
+            out.append("Convergence Reached at Year %d!" % self.final_year)
+        return out
+
+    def top_buses(self, k: int = 5):
+        """[(bus number 1-based, EENS MWh/yr)] of the k worst buses, seqMain.m:221-228 (zero entries are not listed)."""
+        order = np.argsort(-self.nodal_eens_avg, kind="stable")[:k]
+        return [(int(i) + 1, float(self.nodal_eens_avg[i])) for i in order if self.nodal_eens_avg[i] > 0]
+
+    def top_components(self, k: int = 5, numGenerators: int = 33):
+        """[(type, id 1-based, P(down | loss hour))] of the k most critical components, seqMain.m:235-245."""
+        order = np.argsort(-self.comp_importance, kind="stable")[:k]
+        return [(("Gen", int(c) + 1) if c < numGenerators else ("Line", int(c) - numGenerators + 1)) + (float(self.comp_importance[c]),) for c in order]
+
+    def report(self, progress_every: int = 10, numGenerators: int = 33) -> str:
+        """Text of seqMain.m's console output from the yearly loop on (:187-197 progress, :206-249 results, nodal indices, weak points),
+        same wording and number formats."""
+        L = list(self.progress_lines(progress_every))
+        L += ["", "--- SIMULATION COMPLETE ---",
+              "EENS (Expected Energy Not Supplied): %.4f MWh/yr" % self.eens,
+              "LOLE (Loss of Load Expectation):     %.4f hr/yr" % self.lole,
+              "LOLF (Loss of Load Frequency):       %.4f occ/yr" % self.lolf, "", "--- NODAL RELIABILITY INDICES ---",
+              "Top 5 Buses by EENS (MWh/yr):"]
+        L += ["  Bus %2d: %.4f MWh/yr" % bv for bv in self.top_buses(5)]
+        L += ["", "--- WEAK POINT DETECTION ---"]
+        if self.total_loss_hours > 0:
+            L.append("Top 5 Critical Components (Prob. Down given System Failure):")
+            L += ["  %s %2d: %.2f%%" % (t, i, v * 100.0) for t, i, v in self.top_components(5, numGenerators)]
+        else:
+            L.append("No failure events recorded to analyze weak points.")
+        return "\n".join(L)
+
     def write_nodal_csv(self, path: str) -> None:
         """seq_nodal_results.csv as seqMain.m:255-257."""
         with open(path, "w") as f:

@@ -327,6 +327,30 @@ def test_nsqmain_report_wording():
     assert "No failure events recorded to analyze weak points." in quiet.report()
 
 
+def test_seqmain_report_wording():
+    """The console output of seqMain.m:187-197, 206-249 from a result object (host formatting only, no device)."""
+    from powersystemsreliabilityassessment_amd import seq
+    n = 23
+    nodal = np.zeros(24); nodal[[17, 14, 5]] = [499.7, 433.75, 325.15]
+    imp = np.zeros(71); imp[[22, 23, 32, 43, 11]] = [0.45, 0.46, 0.30, 0.22, 0.16]
+    ens = np.linspace(1000.0, 8000.0, n); cum = np.cumsum(ens) / np.arange(1, n + 1)
+    cov = np.linspace(0.5, 0.049, n); cov[0] = 0.0
+    r = seq.SeqResult(final_year=n, eens=float(cum[-1]), cov=0.049, lole=14.3309, lolf=2.4651, results_year=dict(ens=ens, dlc=np.ones(n), nlc=np.ones(n)),
+                      results_cum=dict(eens=cum, cov=cov), nodal_eens_avg=nodal, comp_importance=imp, total_loss_hours=330, years_evaluated=n, n_lp=1000,
+                      n_singular=3, n_infeasible=0, n_nonconverged=0, elapsed_time=0.1, kernel_seconds=0.05, converged=True)
+    rep = r.report().splitlines()
+    assert rep[0] == "Year   10 | EENS: %.4f MWh/yr | CoV: %.4f" % (cum[9], cov[9]) and rep[1].startswith("Year   20 |")       # seqMain.m:187-190
+    assert rep[2] == "Convergence Reached at Year 23!"                                                                        # :195
+    assert "EENS (Expected Energy Not Supplied): %.4f MWh/yr" % cum[-1] in rep and "LOLE (Loss of Load Expectation):     14.3309 hr/yr" in rep
+    assert "LOLF (Loss of Load Frequency):       2.4651 occ/yr" in rep
+    assert rep[rep.index("Top 5 Buses by EENS (MWh/yr):") + 1] == "  Bus 18: 499.7000 MWh/yr" and sum(1 for ln in rep if ln.startswith("  Bus")) == 3
+    k = rep.index("Top 5 Critical Components (Prob. Down given System Failure):")
+    assert rep[k + 1:k + 6] == ["  Gen 24: 46.00%", "  Gen 23: 45.00%", "  Gen 33: 30.00%", "  Line 11: 22.00%", "  Gen 12: 16.00%"]
+    import dataclasses
+    quiet = dataclasses.replace(r, total_loss_hours=0, converged=False)
+    assert "No failure events recorded to analyze weak points." in quiet.report() and "Convergence Reached" not in quiet.report()
+
+
 def test_bench_counter_fields_come_from_the_committed_profile():
     """bench.py's pipe utilisations / traffic are read from profiles/<current>/ and say so; every workload has them."""
     import bench
