@@ -65,38 +65,74 @@ int rccl_fail(relmc_ctx* ctx, const char* what, int rc)
 // Wall-clock guard of one blocking step of the collective path.  A collective whose peer never arrives cannot be cancelled from inside
 // (ncclCommInitRank has no communicator to abort yet; a host callback is the host's code), and a rank that hangs keeps every other rank
 // and the launcher waiting: on expiry the rank says who it is, which GPU it drives and what it was waiting for, and leaves with exit
-// code 86.  A fresh start is the launcher's business.
+// code 86.  A fresh start is the launcher's business.  One watchdog thread per context, started at the first guarded call and parked on
+// a condition variable between calls: arming and disarming it costs two mutex round trips, not a thread.
+struct Watchdog {
+    std::mutex m; std::condition_variable cv; std::thread th;
+    bool armed = false, stop = false; unsigned long long epoch = 0;
+    std::chrono::steady_clock::time_point deadline; double limit = 0.0;
+    std::string what, pci; int device = -1, nranks = 1, rank = 0;
+    void run()
+    {
+        std::unique_lock<std::mutex> lk(m);
+        for (;;) {
+            cv.wait(lk, [this]() { return armed || stop; });
+            if (stop) return;
+            const unsigned long long e = epoch;
+            if (cv.wait_until(lk, deadline, [this, e]() { return stop || !armed || epoch != e; })) { if (stop) return; continue; }
+            std::fprintf(stderr, "relmc_comm: rank %d of %d (pid %d, device %d, PCI %s) has waited %.0f s in %s: a peer never arrived (wrong rank count, a rank that "
+                                 "died or took another path, two ranks on one GPU, or the fabric).  Leaving with exit code 86; relmc_comm_set_timeout changes the limit.\n",
+                         rank, nranks, (int)getpid(), device, pci.c_str(), limit, what.c_str());
+            std::fflush(stderr);
+            _exit(86);
+        }
+    }
+};
+Watchdog* watchdog_of(relmc_ctx* ctx)
+{
+    if (!ctx->watchdog) {
+        Watchdog* w = new Watchdog();
+        char pci[64] = "?";
+        (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), ctx->device);
+        w->pci = pci; w->device = ctx->device;
+        w->th = std::thread([w]() { w->run(); });
+        ctx->watchdog = w;
+    }
+    return static_cast<Watchdog*>(ctx->watchdog);
+}
 struct Guard {
-    std::mutex m; std::condition_variable cv; bool done = false; std::thread th;
-    Guard(const relmc_ctx* ctx, const char* what, int nranks, int rank)
+    Watchdog* w = nullptr;
+    Guard(relmc_ctx* ctx, const char* what, int nranks, int rank)
     {
         const double limit = ctx->comm_timeout_s;
         if (!(limit > 0)) return;
-        char pci[64] = "?";
-        (void)hipDeviceGetPCIBusId(pci, (int)sizeof(pci), ctx->device);
-        const std::string w = what, p = pci; const int dev = ctx->device;
-        th = std::thread([this, limit, w, p, dev, nranks, rank]() {
-            std::unique_lock<std::mutex> lk(m);
-            if (cv.wait_for(lk, std::chrono::duration<double>(limit), [this]() { return done; })) return;
-            std::fprintf(stderr, "relmc_comm: rank %d of %d (pid %d, device %d, PCI %s) has waited %.0f s in %s: a peer never arrived (wrong rank count, a rank that "
-                                 "died or took another path, two ranks on one GPU, or the fabric).  Leaving with exit code 86; relmc_comm_set_timeout changes the limit.\n",
-                         rank, nranks, (int)getpid(), dev, p.c_str(), limit, w.c_str());
-            std::fflush(stderr);
-            _exit(86);
-        });
+        w = watchdog_of(ctx);
+        std::lock_guard<std::mutex> lk(w->m);
+        w->what = what; w->nranks = nranks; w->rank = rank; w->limit = limit;
+        w->deadline = std::chrono::steady_clock::now() + std::chrono::duration_cast<std::chrono::steady_clock::duration>(std::chrono::duration<double>(limit));
+        w->armed = true; w->epoch++;
+        w->cv.notify_all();
     }
     ~Guard()
     {
-        if (!th.joinable()) return;
-        { std::lock_guard<std::mutex> lk(m); done = true; }
-        cv.notify_all();
-        th.join();
+        if (!w) return;
+        std::lock_guard<std::mutex> lk(w->m);
+        w->armed = false; w->epoch++;
+        w->cv.notify_all();
     }
 };
 }  // namespace
 
 void comm_free(relmc_ctx* ctx)
 {
+    if (ctx->watchdog) {
+        Watchdog* w = static_cast<Watchdog*>(ctx->watchdog);
+        { std::lock_guard<std::mutex> lk(w->m); w->stop = true; }
+        w->cv.notify_all();
+        if (w->th.joinable()) w->th.join();
+        delete w;
+        ctx->watchdog = nullptr;
+    }
     if (ctx->comm && g_rccl.CommDestroy) (void)g_rccl.CommDestroy(ctx->comm);
     ctx->comm = nullptr;
     if (ctx->dgather) (void)hipFree(ctx->dgather);

@@ -102,6 +102,7 @@ struct relmc_ctx {
     relmc_allreduce_fn host_allreduce = nullptr; void* host_allreduce_user = nullptr;
     int64_t comm_calls = 0; double comm_seconds = 0.0;                                     // all-reduces of relmc_acc through this context, wall time in them
     double comm_timeout_s = 120.0;                                                         // wall-clock guard of communicator init and of every collective
+    void* watchdog = nullptr;                                                              // the guard's thread (relmc_comm.hip), started at the first guarded call
     double* dgather = nullptr; size_t gather_doubles = 0;                                  // device staging of comm_allreduce_f64 (RCCL)
     // sequential track
     bool has_seq = false; relmc::SeqCase hseq; relmc::SeqCase* dseq = nullptr; double* dlf = nullptr;
