@@ -153,7 +153,7 @@ def tune_order(case: case24.Case, evaluations: int = 20000, seed: int = 1, start
 class Engine:
     """One context = one GPU (one process per GPU).  Owns the device-resident case tables."""
 
-    def __init__(self, case: case24.Case | None = None, device: int = 0, elim_order="case"):
+    def __init__(self, case: case24.Case | None = None, device: int = 0, elim_order="case", debug_switches=()):
         self.L = _lib.load()
         h = C.c_void_p()
         rc = self.L.relmc_ctx_create(int(device), C.byref(h))
@@ -164,6 +164,8 @@ class Engine:
         self.device = device
         self.case = None
         self._holder = None
+        for key in debug_switches:              # diagnosis switches that must be in place before the case is loaded (tests: "no_retry")
+            self.debug_set(key)
         self.load_case(case or case24.rts24(), elim_order)
 
     # -- lifetime ---------------------------------------------------------------------------

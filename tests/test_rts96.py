@@ -370,6 +370,37 @@ def test_gpu_second_larger_case_on_one_context_resizes_the_retry_scratch(case96_
 
 
 @pytest.mark.gpu
+def test_gpu_diagnosis_switches_of_a_context(case96_, numfail96):
+    """relmc_debug_set (the test hooks that replaced round 3's environment switches): `no_retry` leaves the states of the numfail fixture with
+    their first-attempt status and no unit re-evaluated; `retry_dense_first` sends the listed units straight to the dense pivoted solve;
+    `nsq_no_stretch` runs nsqMain one launch per batch with the same checkpoints; an unknown switch is refused."""
+    from powersystemsreliabilityassessment_amd import api
+    st = numfail96["matrix"]; N = st.shape[0]
+    plain = api.Engine(case96_)
+    d0, _, i0 = plain.mc_simulation(st, return_info=True)
+    assert plain.retry_stats()[0] == N and (i0["status"] == 0).sum() >= N - 1
+    off = api.Engine(case96_, debug_switches=("no_retry",))       # set before the case is loaded: the order calibration reads it
+    d1, _, i1 = off.mc_simulation(st, return_info=True)
+    assert off.retry_stats() == (0, 0) and (i1["status"] == 2).sum() >= N - 5           # the fixture IS the set of states the primary order fails on
+    np.testing.assert_allclose(d1, d0, rtol=0, atol=1e-5)                               # the curtailment is the optimum either way
+    with pytest.raises(api.RelmcError, match="unknown switch"):
+        off.debug_set("no_such_switch")
+    off.close()
+    plain.debug_set("retry_dense_first")
+    u0 = plain.retry_dense_stats()[0]
+    d2, _, i2 = plain.mc_simulation(st, return_info=True)
+    assert plain.retry_dense_stats()[0] - u0 == N and (i2["status"] == 0).sum() >= N - 3
+    np.testing.assert_allclose(d2, d0, rtol=0, atol=1e-5)
+    plain.debug_set("retry_dense_first", False)
+    a = plain.nsqMain(beta_limit=0.0, max_iterations=6000, samples_per_batch=500, seed=2)
+    plain.debug_set("nsq_no_stretch")
+    b = plain.nsqMain(beta_limit=0.0, max_iterations=6000, samples_per_batch=500, seed=2)
+    assert len(a.beta_history) == len(b.beta_history) == 12 and np.array_equal(a.acc.to_arrays()[0], b.acc.to_arrays()[0])
+    np.testing.assert_allclose(a.beta_history, b.beta_history, rtol=1e-9)
+    plain.close()
+
+
+@pytest.mark.gpu
 def test_gpu96_dense_last_resort_on_the_numfail_states(engine96, oracle96, numfail96):
     """The 51 RTS-96 states the primary static order ends 'numerically failed' on, through the dense partially pivoted solve alone (the
     third retry level, reached by 2 units in 1e9 samples once the further static orders have had their turn): it converges on at least as
