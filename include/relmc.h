@@ -373,7 +373,7 @@ int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* opts, relmc_seq_resu
  * schedule statistics on stderr.  Diagnosis switches -- no second attempt, dense level first, one launch per batch -- exist as test hooks
  * only, relmc_debug_set in csrc/relmc_debug.hip.) */
 int32_t relmc_retry_stats(const relmc_ctx* ctx, int64_t* units_out, int64_t* converged_out);
-/* The kernel's list of non-converged units holds 4096 + (units of the call) / 256 entries.  relmc_nsq_accumulate / relmc_nsq_run
+/* The kernel's list of non-converged units holds 4096 + (units of the call) / 256 entries (at most 2^20 to begin with).  relmc_nsq_accumulate / relmc_nsq_run
  * (every sample solved) evaluate a chunk again with a longer list if it overflows; the other entry points leave the units beyond the
  * list with their first-attempt results and count them here (0 on every case relmc_case_load calibrated: its primary order fails on at
  * most 0.1 % of the states). */

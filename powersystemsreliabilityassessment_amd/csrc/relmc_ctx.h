@@ -160,7 +160,7 @@ int case_load_image(relmc_ctx* ctx, const relmc_case_desc* d, int order_variant)
 inline int mask_words(const relmc_ctx* ctx) { return ctx->tile == 0 ? Tile24::OW : Tile96::OW; }
 
 // ---- relmc_retry.hip ----------------------------------------------------------------------------------------------------------
-constexpr uint32_t kFailCapMin = 4096, kFailCapMax = 1u << 26;
+constexpr uint32_t kFailCapMin = 4096, kFailCapSteady = 1u << 20, kFailCapMax = 1u << 26;
 uint32_t fail_cap_for(int64_t call_units);
 int fail_list_ensure(relmc_ctx* ctx, uint32_t cap);
 struct RetryOut { std::vector<FailRec> rec; std::vector<double> dns, nodal; std::vector<int32_t> meta; };   // meta = status | relaxed << 2 | iterations << 8

@@ -29,8 +29,10 @@ void retry_free(relmc_ctx* ctx)
 // first-attempt results in relmc_retry_overflow.
 uint32_t fail_cap_for(int64_t call_units)
 {
+    // steady-state size: 4096 + 1/256 of the call's units, at most 2^20 entries (48 MB; a 1e9-sample call used to hold 190 MB for a list that a
+    // calibrated case fills to a few hundred entries).  The fused path grows the list up to kFailCapMax and re-runs the chunk if it overflows.
     const int64_t c = (int64_t)kFailCapMin + call_units / 256;
-    return c > (int64_t)kFailCapMax ? kFailCapMax : (uint32_t)c;
+    return c > (int64_t)kFailCapSteady ? kFailCapSteady : (uint32_t)c;
 }
 int fail_list_ensure(relmc_ctx* ctx, uint32_t cap)
 {
