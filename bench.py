@@ -370,7 +370,7 @@ def secondary_workloads(eng24, device, opts, seed, steps=3):
     res["hl1"] = {"workload": f"HL1 copper-sheet non-sequential MCS on IEEE RTS-24, {N1} iterations x 8736-h load curve per step (BASELINE configs[0])",
                   "value": N1 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3, "kernel": "relmc_hl1_kernel", "kernel_ms_avg": kms, "steps": steps,
                   "lole_h_per_yr": float(np.mean([r.lole_hours_yr for r in rs])), "eue_mwh_per_yr": float(np.mean([r.eue_mwh_yr for r in rs])),
-                  "exact_lole_eue": [9.3941, 1176.29], "includes": "per-iteration LOLE history copied to the host (the reference's convergence history, :202-204)"}
+                  "exact_lole_eue": [9.3941, 1176.29], "includes": "per-iteration LOLE history copied to the host (the reference's convergence history, :202-204); the fleet and the load curve are loaded once"}
     return res
 
 

@@ -122,8 +122,11 @@ def run_non_sequential_mc(gens, load: LoadModel, iterations: int, *, seed: int =
     cap = np.ascontiguousarray([g.capacity for g in gens], dtype=np.float64)
     forr = np.ascontiguousarray([g.for_rate for g in gens], dtype=np.float64)
     hl = np.ascontiguousarray(load.hourly_load, dtype=np.float64)
-    eng._check(L.relmc_hl1_load(eng._h, cap.size, cap.ctypes.data_as(_abi.c_double_p), forr.ctypes.data_as(_abi.c_double_p),
-                                hl.size, hl.ctypes.data_as(_abi.c_double_p)), "relmc_hl1_load")
+    key = (cap.tobytes(), forr.tobytes(), hl.tobytes())
+    if getattr(eng, "_hl1_loaded", None) != key:           # the fleet and the sorted load curve stay on the device between calls on the same model
+        eng._check(L.relmc_hl1_load(eng._h, cap.size, cap.ctypes.data_as(_abi.c_double_p), forr.ctypes.data_as(_abi.c_double_p),
+                                    hl.size, hl.ctypes.data_as(_abi.c_double_p)), "relmc_hl1_load")
+        eng._hl1_loaded = key
     acc = Hl1Acc()
     it_lole = np.zeros(iterations)
     eng._check(L.relmc_hl1_nsq(eng._h, int(seed), 0, int(iterations), C.byref(acc), it_lole.ctypes.data_as(_abi.c_double_p), None),
