@@ -224,13 +224,16 @@ def main():
     ttc_multi = None
     if world > 1 and args.workload == "nsq24" and not args.no_time_to_cov:
         sync()
+        # convergence check every 32 768 samples per rank = four full rounds of the 16-lane tile's grid (8 192 scenario rows): whole-round launches
+        # are the efficient ones (a launch costs as many rounds as its busiest wavefront walks), and one all-reduce per check
+        ttc_batch = 32_768 * world
         t1 = time.perf_counter()
         # with a communicator in the context the loop runs below the C ABI (relmc_nsq_run shards and all-reduces); otherwise in Python
         idx, tot, hist = rdist.nsq_run_distributed(lambda s, lo, n: eng.nsq_accumulate(s, lo, n, opts), case.nb, case.ncomp, seed=args.seed,
-                                                   beta_limit=0.01, max_samples=50_000_000, batch=100_000 * world, device=device,
+                                                   beta_limit=0.01, max_samples=50_000_000, batch=ttc_batch, device=device,
                                                    allreduce=allreduce, engine=eng if comm is not None else None, mpopt=opts)
         sync()
-        ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": 100_000 * world,
+        ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": ttc_batch,
                      "loop": "relmc_nsq_run (below the C ABI)" if comm is not None else "dist.nsq_run_distributed (Python)"}
 
     if rank == 0:
