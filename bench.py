@@ -52,8 +52,9 @@ def main():
                     help="nsq24 = BASELINE configs[1] (the headline, default); rts96 = configs[4] shape; seq = configs[3] shape")
     ap.add_argument("--years", type=int, default=125, help="seq workload: simulated years per GPU per step")
     ap.add_argument("--backend", default="nccl", help="process-group backend (nccl = RCCL; gloo only to exercise the N > 1 path on a 1-GPU box)")
-    ap.add_argument("--comm", choices=["native", "torch", "host"], default="native",
-                    help="who all-reduces relmc_acc when N > 1: native (default) = the library's own RCCL communicator (relmc_comm_*: the north star's "
+    ap.add_argument("--comm", choices=["auto", "native", "torch", "host"], default="auto",
+                    help="who all-reduces relmc_acc when N > 1: auto (default) = native, and if RCCL refuses to build the communicator (an error, not a hang) "
+                         "every rank agrees over the rendezvous to fall back to `host` and the line says so in comm.fallback; native = the library's own RCCL communicator (relmc_comm_*: the north star's "
                          "single RCCL all-reduce over xGMI, no host staging; the 128-byte id travels over a gloo group, torch holds NO nccl group in the "
                          "process: one RCCL user); torch = torch.distributed's collective on the process group; host = torch's collective registered "
                          "with the library as the host transport (relmc_comm_set_host_allreduce).  native / host run the multi-rank nsqMain loop "
@@ -89,7 +90,7 @@ def main():
     device = torch.device("cuda", local_rank)
     # --comm native: ONE RCCL user in the process (the library's communicator), so torch gets a gloo group for the rendezvous,
     # the barriers and the max over ranks of the elapsed time
-    pg_backend = "gloo" if args.comm == "native" else args.backend
+    pg_backend = "gloo" if args.comm in ("native", "auto") else args.backend
     guard = lambda what: rdist.Watchdog(args.comm_timeout, what, rank=rank, world=world, device=local_rank)
     if world > 1:
         with guard(f"torch.distributed.init_process_group({pg_backend})"):
@@ -113,14 +114,29 @@ def main():
     eng = api.Engine(case, device=local_rank)
     eng.comm_set_timeout(args.comm_timeout)
     comm = None
+    comm_fallback = None
     if world > 1 and args.comm != "torch":
+        err = ""
         try:
             # native: RCCL through the C ABI, the unique id travels over the gloo group; host: torch's collective as the library's transport
-            comm = rdist.NativeComm(eng, rank, world) if args.comm == "native" else rdist.HostComm(eng, rank, world, device)
+            comm = rdist.NativeComm(eng, rank, world) if args.comm in ("native", "auto") else rdist.HostComm(eng, rank, world, device)
         except api.RelmcError as e:
-            # no hang, no retry: every rank reports what RCCL said and leaves with a non-zero code
+            err = str(e)
             print(f"bench.py: rank {rank}: communicator init failed: {e}", file=sys.stderr, flush=True)
-            sys.exit(3)
+            if args.comm != "auto":
+                sys.exit(3)          # no hang, no retry: every rank reports what RCCL said and leaves with a non-zero code
+        if args.comm == "auto":
+            # did every rank get its communicator?  One gather over the rendezvous; if any did not, ALL fall back to the host collective
+            # (torch's gloo all-reduce registered as the library's transport: host-staged, always available) -- loudly, and the line records it
+            box_ = [None] * world
+            with guard("all_gather of the communicator-init outcomes"):
+                dist.all_gather_object(box_, err)
+            if any(box_):
+                if comm is not None:
+                    comm.close()
+                comm_fallback = next(m for m in box_ if m)
+                print(f"bench.py: rank {rank}: falling back to --comm host (the library's loop over torch's gloo collective): {comm_fallback}", file=sys.stderr, flush=True)
+                comm = rdist.HostComm(eng, rank, world, device)
     ar_seconds, ar_calls = [0.0], [0]
 
     def allreduce(acc):
@@ -216,6 +232,8 @@ def main():
     comm_info["allreduce_bytes"] = _C.sizeof(_rabi.Acc)
     comm_info["devices"] = devices
     comm_info["timeout_s"] = args.comm_timeout
+    if comm_fallback:
+        comm_info["fallback"] = "native communicator refused, host collective used instead: " + comm_fallback
     if comm_info["nranks_seen"] != world:
         print(f"bench.py: rank {rank}: the communicator reports {comm_info['nranks_seen']} ranks, the launcher {world}", file=sys.stderr, flush=True)
         sys.exit(4)

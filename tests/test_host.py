@@ -298,10 +298,14 @@ def test_bench_comm_paths_are_self_evidencing(tmp_path):
     q1, c1 = run(1, ["--workload", "seq", "--years", "16", "--no-time-to-cov"], "q1")
     assert q2["unit"] == "hourly DC-OPFs/s" and q2["comm"]["nranks_seen"] == 2 and q2["indices"]["n"] == q1["indices"]["n"] > 0 and c2["ints"] == c1["ints"]
     np.testing.assert_allclose([float.fromhex(x) for x in c2["dbls"]], [float.fromhex(x) for x in c1["dbls"]], rtol=1e-11, atol=1e-9)
-    bad = run(2, ["--batch", "20000", "--no-time-to-cov"], "x2", expect_ok=False)          # --comm native is the default for N > 1
+    bad = run(2, ["--batch", "20000", "--comm", "native", "--no-time-to-cov"], "x2", expect_ok=False)
     assert bad.returncode != 0
     assert bad.stderr.count("communicator init failed") >= 1 and "ncclCommInitRank" in bad.stderr, bad.stderr[-1500:]
     assert '"metric"' not in bad.stdout
+    # the default for N > 1 (--comm auto) tries the same, and when RCCL refuses every rank agrees to fall back to the host collective -- and says so
+    f2, fa = run(2, ["--batch", "50000", "--no-time-to-cov"], "f2")
+    assert f2["comm"]["backend"] == "host-collective" and "ncclCommInitRank" in f2["comm"]["fallback"] and f2["comm"]["nranks_seen"] == 2
+    assert fa["ints"] == a1["ints"]
 
 
 def test_nsqmain_report_wording():
