@@ -117,13 +117,19 @@ def main():
     comm_fallback = None
     if world > 1 and args.comm != "torch":
         err = ""
-        try:
-            # native: RCCL through the C ABI, the unique id travels over the gloo group; host: torch's collective as the library's transport
-            comm = rdist.NativeComm(eng, rank, world) if args.comm in ("native", "auto") else rdist.HostComm(eng, rank, world, device)
-        except api.RelmcError as e:
-            err = str(e)
-            print(f"bench.py: rank {rank}: communicator init failed: {e}", file=sys.stderr, flush=True)
-            if args.comm != "auto":
+        if args.comm == "auto":
+            # the deadline is bench.py's here (a helper thread around relmc_comm_init): a stall must end in the fallback, not in the library's exit
+            eng.comm_set_timeout(0)
+            comm, err = rdist.NativeComm.try_init(eng, rank, world, args.comm_timeout if args.comm_timeout > 0 else 0)
+            eng.comm_set_timeout(args.comm_timeout)
+            if err:
+                print(f"bench.py: rank {rank}: communicator init failed: {err}", file=sys.stderr, flush=True)
+        else:
+            try:
+                # native: RCCL through the C ABI, the unique id travels over the gloo group; host: torch's collective as the library's transport
+                comm = rdist.NativeComm(eng, rank, world) if args.comm == "native" else rdist.HostComm(eng, rank, world, device)
+            except api.RelmcError as e:
+                print(f"bench.py: rank {rank}: communicator init failed: {e}", file=sys.stderr, flush=True)
                 sys.exit(3)          # no hang, no retry: every rank reports what RCCL said and leaves with a non-zero code
         if args.comm == "auto":
             # did every rank get its communicator?  One gather over the rendezvous; if any did not, ALL fall back to the host collective
@@ -132,8 +138,14 @@ def main():
             with guard("all_gather of the communicator-init outcomes"):
                 dist.all_gather_object(box_, err)
             if any(box_):
-                if comm is not None:
+                stalled_any = any("stalled" in m for m in box_ if m)
+                if comm is not None and not stalled_any:
                     comm.close()
+                elif comm is not None or "stalled" in err:
+                    # a context whose communicator cannot be destroyed safely (a peer is stuck inside RCCL) or whose init call is still
+                    # running on the abandoned thread is left alone for good: the fallback gets a context of its own
+                    eng = api.Engine(case, device=local_rank)
+                    eng.comm_set_timeout(args.comm_timeout)
                 comm_fallback = next(m for m in box_ if m)
                 print(f"bench.py: rank {rank}: falling back to --comm host (the library's loop over torch's gloo collective): {comm_fallback}", file=sys.stderr, flush=True)
                 comm = rdist.HostComm(eng, rank, world, device)
@@ -337,6 +349,9 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
+    if rdist.abandoned_threads():
+        sys.stdout.flush(); sys.stderr.flush()
+        os._exit(0)              # a helper thread is still inside a stalled RCCL call: do not wait for it at interpreter exit
 
 
 def secondary_workloads(eng24, device, opts, seed, steps=3):

@@ -65,6 +65,13 @@ def _broadcast_bytes(payload, rank: int, world: int, key: str = "relmc_comm_id")
     return bytes(store.get(key))
 
 
+_ABANDONED = []          # helper threads left inside a stalled RCCL call (NativeComm.try_init)
+
+
+def abandoned_threads() -> int:
+    return len(_ABANDONED)
+
+
 class NativeComm:
     """The library's own RCCL communicator (relmc_comm_*, include/relmc.h): what a Julia / C host would use.  Only the 128-byte
     unique id is exchanged through the host's rendezvous (`_broadcast_bytes`); the process needs no torch `nccl` group beside it
@@ -81,6 +88,28 @@ class NativeComm:
             engine._check(engine.L.relmc_comm_unique_id(uid), "relmc_comm_unique_id")
         uid = (C.c_uint8 * 128).from_buffer_copy(_broadcast_bytes(bytes(uid), rank, world))
         engine._check(engine.L.relmc_comm_init(engine._h, world, rank, uid), "relmc_comm_init")
+
+    @classmethod
+    def try_init(cls, engine, rank: int, world: int, seconds: float):
+        """The same with a deadline, for hosts that have a second transport to fall back to: (communicator, "") or (None, why).  The blocking
+        relmc_comm_init runs on a helper thread; RCCL's error comes back as text, and if the call has not returned after `seconds` (RCCL's
+        bootstrap has been seen to stall) the thread is ABANDONED -- it cannot be cancelled, the process never calls RCCL again -- and the
+        caller is told "stalled" (`abandoned_threads()` > 0 then: leave the process with os._exit when done).  seconds <= 0: no deadline."""
+        import threading
+        box = {}
+
+        def work():
+            try:
+                box["comm"] = cls(engine, rank, world)
+            except Exception as e:                     # RelmcError with RCCL's message, or whatever the rendezvous raised
+                box["err"] = f"{type(e).__name__}: {e}"
+        th = threading.Thread(target=work, daemon=True)
+        th.start()
+        th.join(seconds if seconds and seconds > 0 else None)
+        if th.is_alive():
+            _ABANDONED.append(th)
+            return None, f"relmc_comm_init (ncclCommInitRank) had not returned after {seconds:.0f} s: stalled, thread abandoned"
+        return box.get("comm"), box.get("err", "")
 
     def allreduce_acc(self, acc: _abi.Acc) -> _abi.Acc:
         import ctypes as C
