@@ -299,7 +299,8 @@ int32_t relmc_ctx_create(int32_t device_id, relmc_ctx** out)
     if (hipSetDevice(device_id) != hipSuccess || hipGetDeviceProperties(&prop, device_id) != hipSuccess ||
         hipStreamCreateWithFlags(&ctx->stream, hipStreamNonBlocking) != hipSuccess ||
         hipEventCreate(&ctx->ev0) != hipSuccess || hipEventCreate(&ctx->ev1) != hipSuccess ||
-        hipMalloc(&ctx->dcase, sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess) {
+        hipMalloc(&ctx->dcase, sizeof(DevCaseT<Tile96>) > sizeof(DevCaseT<Tile24>) ? sizeof(DevCaseT<Tile96>) : sizeof(DevCaseT<Tile24>)) != hipSuccess || hipMalloc(&ctx->dacc, sizeof(DevAcc)) != hipSuccess ||
+        hipHostMalloc(reinterpret_cast<void**>(&ctx->hstage), sizeof(relmc_ctx::HostStage), hipHostMallocDefault) != hipSuccess) {
         relmc_ctx_destroy(ctx);          // releases whatever was created before the failure
         return RELMC_ERR_NO_DEVICE;
     }
@@ -319,6 +320,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     if (ctx->dpartial) (void)hipFree(ctx->dpartial);
     if (ctx->dcase) (void)hipFree(ctx->dcase);
     if (ctx->dacc) (void)hipFree(ctx->dacc);
+    if (ctx->hstage) (void)hipHostFree(ctx->hstage);
     if (ctx->dtiming) (void)hipFree(ctx->dtiming);
     if (ctx->dhist) (void)hipFree(ctx->dhist);
     if (ctx->hhist) (void)hipHostFree(ctx->hhist);

@@ -50,6 +50,7 @@ struct relmc_ctx {
     void* dpartial = nullptr;
     size_t partial_bytes = 0;
     relmc::DevAcc* dacc = nullptr;
+    struct HostStage { relmc_acc acc; uint32_t fail_cnt, pad; }* hstage = nullptr;      // pinned: accumulators + listed-unit count of a fused launch come back in one synchronisation
     int num_cu = 0;
     int blocks_per_cu = 0;
     uint32_t scen_doubles = 0, lds_bytes = 0, stash_off = 0;
@@ -168,7 +169,8 @@ int alt_ensure(relmc_ctx* ctx, int v);
 int fail_arm(relmc_ctx* ctx, EvalArgs& a, int64_t unit_base, bool reset, int64_t call_units);
 int fail_listed(relmc_ctx* ctx, uint32_t* cnt);
 using ScaleFn = std::function<double(unsigned long long)>;          // unit -> load scale factor of a re-evaluated unit
-int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold, const ScaleFn* scale, RetryOut& out, double* ms);
+// known_count (optional): the number of listed units if the caller has already copied it back with its results
+int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold, const ScaleFn* scale, RetryOut& out, double* ms, const uint32_t* known_count = nullptr);
 void acc_add_unit(relmc_acc* acc, const FailRec& rec, double dns, int32_t meta, const double* nodal, int nb, int ncomp, double fail_threshold);
 void retry_free(relmc_ctx* ctx);
 

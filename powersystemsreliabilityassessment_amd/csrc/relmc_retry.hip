@@ -93,14 +93,15 @@ int fail_listed(relmc_ctx* ctx, uint32_t* cnt)
 
 // After the launches of a call have completed: the listed units (ascending), evaluated under the second order.  `scale` (optional) maps a
 // unit to its load scale factor.  out.rec is empty when nothing was listed.  Adds the retry kernel's time to *ms.
-int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold, const ScaleFn* scale_fn, RetryOut& out, double* ms)
+int fail_retry(relmc_ctx* ctx, const relmc_solver_opts& o, double fail_threshold, const ScaleFn* scale_fn, RetryOut& out, double* ms, const uint32_t* known_count)
 {
     const bool have_scale = scale_fn != nullptr;
     auto scale = [&](unsigned long long u) { return (*scale_fn)(u); };
     out.rec.clear();
     if (!ctx->dfail_count) return RELMC_OK;
     uint32_t cnt = 0;
-    HIP_TRY(ctx, hipMemcpy(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost));
+    if (known_count) cnt = *known_count;            // the caller read the count with its results (one synchronisation)
+    else HIP_TRY(ctx, hipMemcpy(&cnt, ctx->dfail_count, sizeof(cnt), hipMemcpyDeviceToHost));
     ctx->fail_dirty = false;
     if (cnt == 0) return RELMC_OK;
     HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));

@@ -150,6 +150,7 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
         a.dns = dns_dev ? dns_dev + done : nullptr;
         int blocks = 0;
         relmc_acc part;
+        uint32_t listed = 0;
         for (int attempt = 0;; ++attempt) {
             int rc = fail_arm(ctx, a, done, true, m);
             if (rc) return rc;
@@ -157,15 +158,17 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
             if (rc) return rc;
             rc = launch_finalize(ctx, blocks);
             if (rc) return rc;
-            HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
+            // accumulators and the count of listed units come back in ONE synchronisation, through the context's pinned staging words (two more
+            // blocking 4-byte copies per launch used to follow the kernel)
+            HIP_TRY(ctx, hipMemcpyAsync(&ctx->hstage->acc, ctx->dacc, sizeof(relmc_acc), hipMemcpyDeviceToHost, ctx->stream));
+            if (a.fail_count) HIP_TRY(ctx, hipMemcpyAsync(&ctx->hstage->fail_cnt, ctx->dfail_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream));
             rc = finish_timing(ctx);
             if (rc) return rc;
             ms_total += ctx->last_kernel_ms;
+            part = ctx->hstage->acc;
             // more non-converged units than the list holds (a case the calibration did not foresee): a longer list and the same chunk again --
             // the launch is a function of (seed, range) alone, so the second one lists them all
-            uint32_t listed = 0;
-            rc = fail_listed(ctx, &listed);
-            if (rc) return rc;
+            listed = a.fail_count ? ctx->hstage->fail_cnt : 0u;
             if (a.fail_list == nullptr || listed <= ctx->fail_cap || ctx->fail_cap >= kFailCapMax || attempt >= 2) break;
             HIP_TRY(ctx, hipMemset(ctx->dfail_count, 0, sizeof(uint32_t)));
             rc = fail_list_ensure(ctx, listed + listed / 8 > kFailCapMax ? kFailCapMax : listed + listed / 8);
@@ -173,7 +176,7 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
         }
         int rc = RELMC_OK;
         RetryOut ro;
-        rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total);
+        rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total, a.fail_count ? &listed : nullptr);
         if (rc) return rc;
         for (size_t r = 0; r < ro.rec.size(); ++r) {
             acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);
