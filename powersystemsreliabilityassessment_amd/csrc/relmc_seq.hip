@@ -156,13 +156,17 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         if (rc) { cleanup(); return rc; }
         rc = launch_eval(ctx, 2, a, &blocks);
         if (rc) { cleanup(); return rc; }
-        if (launch_finalize(ctx, blocks) != RELMC_OK || hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
+        // accumulators and the count of listed hours in one synchronisation (pinned staging), as in the fused non-sequential pass
+        if (launch_finalize(ctx, blocks) != RELMC_OK || hipMemcpyAsync(&ctx->hstage->acc, ctx->dacc, sizeof(relmc_acc), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+            (a.fail_count && hipMemcpyAsync(&ctx->hstage->fail_cnt, ctx->dfail_count, sizeof(uint32_t), hipMemcpyDeviceToHost, ctx->stream) != hipSuccess)) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: finalize failed"); }
         rc = finish_timing(ctx);
         if (rc) { cleanup(); return rc; }
+        *acc_out = ctx->hstage->acc;
+        const uint32_t listed = a.fail_count ? ctx->hstage->fail_cnt : 0u;
         ms = ctx->last_kernel_ms;
         RetryOut ro;                                                   // hours the primary elimination order did not converge on
         const ScaleFn scale = [&](unsigned long long u) { return ctx->hlf[(size_t)(u % (unsigned long long)hpy)]; };
-        rc = fail_retry(ctx, o, curtail_threshold, &scale, ro, &ms);
+        rc = fail_retry(ctx, o, curtail_threshold, &scale, ro, &ms, a.fail_count ? &listed : nullptr);
         if (rc) { cleanup(); return rc; }
         for (size_t r = 0; r < ro.rec.size(); ++r) {
             acc_add_unit(acc_out, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, curtail_threshold);

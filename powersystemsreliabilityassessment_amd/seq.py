@@ -111,8 +111,8 @@ class SeqEngine:
         acc = _abi.Acc()
         self.eng._check(self.L.relmc_seq_years(self.eng._h, int(seed), int(first_year), int(n_years), C.byref(o), float(curtail_threshold),
                                                yrs, C.byref(acc)), "relmc_seq_years")
-        a = np.array([(y.ens, y.dlc, y.nlc, y.n_contingency) for y in yrs], dtype=np.float64).reshape(-1, 4)
-        return a[:, 0], a[:, 1], a[:, 2], a[:, 3].astype(np.int64), acc
+        raw = np.frombuffer(yrs, dtype=np.dtype([("ens", "<f8"), ("dlc", "<f8"), ("nlc", "<f8"), ("n_contingency", "<i8")]), count=int(n_years))
+        return raw["ens"].copy(), raw["dlc"].copy(), raw["nlc"].copy(), raw["n_contingency"].copy(), acc
 
     # seqMain.m:85-262
     def seqMain(self, max_sim_years: int = MAX_SIM_YEARS, cov_threshold: float = COV_THRESHOLD,
@@ -134,7 +134,8 @@ class SeqEngine:
         res = _abi.SeqResult()
         self.eng._check(self.L.relmc_seq_run(self.eng._h, C.byref(o), C.byref(res)), "relmc_seq_run")
         y = int(res.final_year)
-        a = np.array([(q.ens, q.dlc, q.nlc) for q in yrs[:y]], dtype=np.float64).reshape(-1, 3)
+        raw = np.frombuffer(yrs, dtype=np.dtype([("ens", "<f8"), ("dlc", "<f8"), ("nlc", "<f8"), ("n_contingency", "<i8")]), count=n)[:y]
+        a = np.column_stack([raw["ens"], raw["dlc"], raw["nlc"]]).reshape(-1, 3)
         nb, nc = self.eng.case.nb, self.eng.case.ncomp
         return SeqResult(
             final_year=y, eens=res.eens, cov=res.cov, lole=res.lole, lolf=res.lolf,
