@@ -137,6 +137,7 @@ struct SymOpts {
     int place_moves = 100;               // moves per block of the LDS placement search (0: the order tuner's cost does not depend on the placement)
     long place_ww = 1;                   // weight of conflicts on operands that are written back
     bool no_quarter = false, no_half = false, no_bwd_half = false, no_bus_map = false;      // schedule forms off (ablation builds)
+    int scen_pad4 = 0;                   // extra padding of a scenario row's LDS stride in units of 4 doubles (ablation builds)
     int model_leaf_free = -1;            // >= 0: scheduling MODEL with the pivots complete at assembly left out (relmc_debug_symbolic only: not a valid program)
 };
 struct SymGeom { uint32_t stash_off = 0, scen_doubles = 0, lds_bytes = 0; long conflict_before = 0, conflict_after = 0; };

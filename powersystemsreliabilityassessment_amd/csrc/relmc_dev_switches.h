@@ -17,5 +17,6 @@ inline void relmc_dev_switches_schedule(relmc_host::SymOpts& so)
     if (const char* q = std::getenv("RELMC_PLACE_WW")) so.place_ww = std::atol(q);
     if (const char* q = std::getenv("RELMC_PLACE_MOVES")) so.place_moves = std::atoi(q);
     so.no_quarter = std::getenv("RELMC_NO_QUARTER") != nullptr; so.no_half = std::getenv("RELMC_NO_HALF") != nullptr;
+    if (const char* q = std::getenv("RELMC_SCEN_PAD4")) so.scen_pad4 = std::atoi(q);
     so.no_bwd_half = std::getenv("RELMC_NO_BWD_HALF") != nullptr; so.no_bus_map = std::getenv("RELMC_NO_BUS_MAP") != nullptr;
 }

@@ -315,6 +315,7 @@ int case_symbolic(const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant, 
             stride = (stride + 1u) & ~1u;
             stride += 2u * IS * ROWL + 2u + NBT + OW / 2u;
             while ((stride & 3u) != 2u) stride += 1;            // = the per-scenario LDS stride computed below
+            stride += 4u * (uint32_t)so.scen_pad4;
             static const int kGroupOfLane[64] = {0,0,0,0,1,1,1,1,1,1,1,1,0,0,0,0, 1,1,1,1,0,0,0,0,0,0,0,0,1,1,1,1,
                                                  2,2,2,2,3,3,3,3,3,3,3,3,2,2,2,2, 3,3,3,3,2,2,2,2,2,2,2,2,3,3,3,3};
             auto remap = [&](int o) {                             // offset under the identity placement -> current placement
@@ -622,6 +623,7 @@ int case_symbolic(const relmc_case_desc* d, DevCaseT<TL>& C, int order_variant, 
     const uint32_t stash_off = scen;
     scen += 2u * IS * ROWL + 2u + NBT + OW / 2u;           // stash: 1/D and Np/D per injection lane (+ one zero pair); lambda per bus; outage mask words
     while ((scen & 3u) != 2u) scen += 1;                  // 16-byte aligned rows (ds_read_b128!) whose 16-B slot index differs by an odd number
+    scen += 4u * (uint32_t)so.scen_pad4;                   // (ablation builds: more padding between the rows, in steps of 32 bytes)
     const uint32_t case_bytes = (uint32_t)offsetof(DevCaseT<TL>, task);     // tables copied to LDS; the pass schedule is read from global memory
     const uint32_t lds_bytes = 128u + ((case_bytes + 15u) & ~15u) + (uint32_t)SPW * WPB * scen * (uint32_t)sizeof(double) + (ROWL == 16 ? (1024u + 64u) * WPB : 0u);   // + sampling window of the fused path   // 128: solver options
     if (lds_bytes > 160u * 1024u) return failx(RELMC_ERR_UNSUPPORTED, "relmc_case_load: case needs more than 160 KiB of LDS per workgroup");
