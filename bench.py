@@ -2,7 +2,10 @@
 """bench.py — headline benchmark of the hot path: Monte Carlo DC-OPF scenarios/sec, IEEE RTS-24.
 
   python bench.py --gpus N --steps K --warmup W
-  (N > 1: launched by the driver as  python -m torch.distributed.run --nproc-per-node N ... bench.py)
+  N > 1 without a launcher: bench.py starts the N ranks itself (`launch_ranks`: N fresh child processes, one per GPU, before anything in the
+  parent has touched torch or the GPU; rank 0's JSON line is the parent's stdout, the parent's exit code is the first failing rank's).
+  Under a launcher (the driver's  python -m torch.distributed.run --nproc-per-node N ... bench.py --gpus N) the ranks are the launcher's;
+  WORLD_SIZE must then equal --gpus.
 
 A "step" is one pass of the fused hot path (sample -> DC-OPF interior point -> accumulate) over one
 batch of `--batch` (default 1e6 = BASELINE.json configs[1]) synthetic scenarios PER GPU, followed
@@ -40,6 +43,80 @@ def dense_flop_per_iter(nb):
     return n ** 3 / 3.0 + 2.0 * n * n + 1.5e3
 
 
+EXIT_WORLD_MISMATCH = 7         # WORLD_SIZE of the launcher != --gpus
+EXIT_TOO_FEW_GPUS = 6           # --gpus exceeds the GPUs of the node (and --share-device was not asked for)
+
+
+def _free_port():
+    import socket
+    with socket.socket(socket.AF_INET, socket.SOCK_STREAM) as s:
+        s.bind(("127.0.0.1", 0))
+        return s.getsockname()[1]
+
+
+def _die_with_parent():
+    """preexec of a rank process: SIGTERM when the parent goes away (a killed bench.py must not leave ranks on the GPUs)."""
+    import ctypes
+    import signal
+    try:
+        ctypes.CDLL("libc.so.6", use_errno=True).prctl(1, signal.SIGTERM, 0, 0, 0)       # PR_SET_PDEATHSIG
+    except OSError:
+        pass
+
+
+def launch_ranks(n, argv, poll=0.05, grace=5.0, script=None):
+    """`bench.py --gpus N` called plainly: the analogue of opening the reference's parfor pool (nsqMain.m:257-263, seqMain.m:112-133).
+    The parent has imported neither torch nor the package and holds no GPU state; it starts N FRESH processes of this very script with the
+    same arguments plus RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT (never a re-exec of itself), lets rank 0
+    write the JSON line to the parent's stdout (the other ranks' stdout goes to stderr), and waits.  The first rank that leaves with a
+    non-zero code (86 = a guarded collective stalled, 3 = communicator refused, 4 = rank-count mismatch, 5 = duplicate GPUs, 6 = too few
+    GPUs) ends the run: the remaining ranks are terminated by pid and the parent exits with that code."""
+    import signal
+    import subprocess
+    port = _free_port()
+    script = script or os.path.abspath(__file__)
+    procs = []
+    for r in range(n):
+        env = dict(os.environ)
+        env.update({"RANK": str(r), "LOCAL_RANK": str(r), "WORLD_SIZE": str(n), "LOCAL_WORLD_SIZE": str(n), "MASTER_ADDR": "127.0.0.1",
+                    "MASTER_PORT": str(port), "RELMC_BENCH_LAUNCHER": "bench.py"})
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+        procs.append(subprocess.Popen([sys.executable, script] + list(argv), env=env, stdout=None if r == 0 else sys.stderr,
+                                      preexec_fn=_die_with_parent))
+
+    def stop_all(*_):
+        for p in procs:
+            if p.poll() is None:
+                p.terminate()
+        t_end = time.time() + grace
+        for p in procs:
+            try:
+                p.wait(max(0.0, t_end - time.time()))
+            except subprocess.TimeoutExpired:
+                p.kill(); p.wait()
+
+    def on_signal(signum, _frame):
+        stop_all()
+        sys.exit(128 + signum)
+    signal.signal(signal.SIGTERM, on_signal)
+    signal.signal(signal.SIGINT, on_signal)
+    code = 0
+    while True:
+        running = 0
+        for r, p in enumerate(procs):
+            rc = p.poll()
+            if rc is None:
+                running += 1
+            elif rc != 0 and code == 0:
+                code = rc if rc > 0 else 128 - rc
+                print(f"bench.py: rank {r} of {n} (pid {p.pid}) left with code {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+        if code or not running:
+            break
+        time.sleep(poll)
+    stop_all()
+    return code
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -62,6 +139,8 @@ def main():
     ap.add_argument("--comm-timeout", type=float, default=120.0, help="wall-clock guard (seconds) of communicator init and of every collective: on expiry the "
                                                                        "rank prints who it is and what it waited for and exits non-zero (0 = off)")
     ap.add_argument("--no-secondary", action="store_true", help="skip the RTS-96 / sequential / HL1 rates measured beside the headline (outside the timed region)")
+    ap.add_argument("--no-sustained", action="store_true", help="skip the sustained-rate leg (one stream of --sustained-samples scenarios, outside the timed region)")
+    ap.add_argument("--sustained-samples", type=int, default=300_000_000, help="scenarios of the sustained-rate leg (>= 2.5e8: more than 4 s of continuous GPU work)")
     ap.add_argument("--share-device", action="store_true", help="testing only: every rank uses GPU 0")
     ap.add_argument("--seed", type=int, default=1)
     ap.add_argument("--policy", choices=["emulate", "physical"], default="emulate")
@@ -70,6 +149,18 @@ def main():
     ap.add_argument("--cpu-sample", type=int, default=0, help="scenarios of the CPU baseline sample (0 = auto)")
     ap.add_argument("--dump-acc", default="", help="testing: rank 0 writes the merged accumulators of the timed steps to this file")
     args = ap.parse_args()
+
+    if args.gpus < 1:
+        ap.error("--gpus must be >= 1")
+    env_world = os.environ.get("WORLD_SIZE")
+    if env_world is None and "RANK" not in os.environ:
+        if args.gpus > 1:
+            # no launcher: this process becomes one (it has not imported torch and never touches a GPU)
+            sys.exit(launch_ranks(args.gpus, sys.argv[1:]))
+    elif int(env_world or "1") != args.gpus:
+        print(f"bench.py: the launcher started WORLD_SIZE={env_world or '1'} ranks but --gpus says {args.gpus}: refusing to report one as the other "
+              f"(call `python bench.py --gpus {args.gpus}` plainly, or give the launcher --nproc-per-node {args.gpus})", file=sys.stderr, flush=True)
+        sys.exit(EXIT_WORLD_MISMATCH)
 
     import torch
     import torch.distributed as dist
@@ -81,7 +172,19 @@ def main():
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
-        os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")      # ONE node: RCCL's bootstrap sockets over loopback (the container's hostname may not resolve); xGMI carries the data
+        if os.environ["MASTER_ADDR"] in ("127.0.0.1", "localhost", "::1"):
+            os.environ.setdefault("NCCL_SOCKET_IFNAME", "lo")  # ONE node: RCCL's bootstrap sockets over loopback (the container's hostname may not resolve); xGMI carries the data
+        if args.comm in ("native", "auto") and args.backend != "gloo":
+            if rank == 0 and args.backend != ap.get_default("backend"):
+                print(f"bench.py: --backend {args.backend} is not used with --comm {args.comm}: the process group is gloo (rendezvous, barriers, max of the elapsed "
+                      f"time), the library's own RCCL communicator carries the all-reduce (ONE RCCL user per process); --comm torch honours --backend", file=sys.stderr, flush=True)
+    n_dev = torch.cuda.device_count()                          # counts devices without initialising one
+    if n_dev < 1:
+        raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
+    if world > n_dev and not args.share_device:
+        print(f"bench.py: rank {rank}: --gpus {world} but this node has {n_dev} GPU{'s' if n_dev != 1 else ''} (torch.cuda.device_count()); "
+              f"--share-device puts every rank on GPU 0 (testing only)", file=sys.stderr, flush=True)
+        sys.exit(EXIT_TOO_FEW_GPUS)
     if not torch.cuda.is_available():
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
     if args.share_device:
@@ -91,13 +194,27 @@ def main():
     # --comm native: ONE RCCL user in the process (the library's communicator), so torch gets a gloo group for the rendezvous,
     # the barriers and the max over ranks of the elapsed time
     pg_backend = "gloo" if args.comm in ("native", "auto") else args.backend
+    if args.share_device and world > 1 and pg_backend == "nccl":
+        pg_backend = "gloo"          # RCCL refuses two ranks on one device ("Duplicate GPU detected"): the rehearsal's process group is gloo
+        if rank == 0:
+            print("bench.py: --share-device: the process group is gloo (RCCL does not accept two ranks on one GPU)", file=sys.stderr, flush=True)
     guard = lambda what: rdist.Watchdog(args.comm_timeout, what, rank=rank, world=world, device=local_rank)
     if world > 1:
-        with guard(f"torch.distributed.init_process_group({pg_backend})"):
-            if pg_backend == "nccl":
-                dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
-            else:
-                dist.init_process_group(pg_backend, rank=rank, world_size=world)
+        # gloo announces its connections on the C stdout ("[Gloo] Rank 0 is connected to ..."): stdout carries ONE line, the JSON one, so file
+        # descriptor 1 points at stderr while the group is built
+        sys.stdout.flush()
+        fd1 = os.dup(1)
+        os.dup2(2, 1)
+        try:
+            with guard(f"torch.distributed.init_process_group({pg_backend})"):
+                if pg_backend == "nccl":
+                    dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
+                else:
+                    dist.init_process_group(pg_backend, rank=rank, world_size=world)
+                dist.barrier() if pg_backend != "nccl" else None          # gloo connects lazily: make it speak now
+        finally:
+            os.dup2(fd1, 1)
+            os.close(fd1)
 
     def sync():
         if world > 1:
@@ -143,7 +260,9 @@ def main():
                     comm.close()
                 elif comm is not None or "stalled" in err:
                     # a context whose communicator cannot be destroyed safely (a peer is stuck inside RCCL) or whose init call is still
-                    # running on the abandoned thread is left alone for good: the fallback gets a context of its own
+                    # running on the abandoned thread is left alone for good: the pair stays referenced for the life of the process (no
+                    # finaliser may reach ncclCommDestroy; the process leaves through os._exit below), the fallback gets a context of its own
+                    rdist.keep_forever(comm, eng)
                     eng = api.Engine(case, device=local_rank)
                     eng.comm_set_timeout(args.comm_timeout)
                 comm_fallback = next(m for m in box_ if m)
@@ -265,6 +384,30 @@ def main():
         sync()
         ttc_multi = {"seconds": time.perf_counter() - t1, "samples": int(tot.n), "beta": idx["beta"], "edns_mw": idx["edns"], "batch": ttc_batch,
                      "loop": "relmc_nsq_run (below the C ABI)" if comm is not None else "dist.nsq_run_distributed (Python)"}
+    # the reference's unique-state database over N ranks (nsqMain.m:220-278): every rank keeps the database of ITS slices, so a state two
+    # ranks meet is solved twice.  Measured here, in the line: rows solved per rank against the rows one database holds for the same samples
+    db_multi = None
+    if world > 1 and args.workload == "nsq24" and not args.no_time_to_cov and comm is not None:
+        sync()
+        t1 = time.perf_counter()
+        rdb = eng.nsqMain(beta_limit=0.0017, max_iterations=50_000_000, samples_per_batch=1_000_000, seed=args.seed, mpopt=opts, distinct_states="database")
+        sync()
+        dtdb = time.perf_counter() - t1
+        box_ = [None] * world
+        with guard("all_gather of the ranks' database sizes"):
+            dist.all_gather_object(box_, int(eng.db_size()[0]))
+        if rank == 0:
+            eng.db_reset()                                            # one database over the same samples: what a single rank would have solved
+            for lo_ in range(0, rdb.current_iteration, 1_000_000):
+                eng.nsq_db_batch(args.seed, lo_, min(1_000_000, rdb.current_iteration - lo_), opts)
+            rows_one = int(eng.db_size()[0])
+            db_multi = {"what": "relmc_nsq_run with distinct_states = database over all ranks, batches of 1e6 samples split over the ranks, to the reference's beta < 0.0017",
+                        "per_rank_database": True, "seconds": dtdb, "samples": rdb.current_iteration, "beta": rdb.current_beta, "edns_mw": rdb.accumulated_edns,
+                        "rows_per_rank": [int(x) for x in box_], "rows_single_database": rows_one,
+                        "redundant_solves_x": sum(int(x) for x in box_) / max(1, rows_one),
+                        "note": "state ownership is not sharded: the path is bound by the sort / lookup of the samples (6e8-1e9 samples/s per GPU), which does shard; "
+                                "the redundant solves are the price of no exchange step (DESIGN.md 4)"}
+        sync()
 
     if rank == 0:
         n_total = int(total.n)
@@ -284,7 +427,10 @@ def main():
                               "(above 1 on RTS-96: that count is avoidable work)",
                 "flop_per_iteration_executed": fl_exec, "flop_per_iteration_dense_equiv": fl_dense, "mean_ipm_iterations": mean_iters,
                 "kernel": kname, "kernel_ms_avg": avg_kernel_s * 1e3, "units_per_launch": units_per_launch}
-        roof.update(counters_from_profile(args.workload, units_per_launch, torch.cuda.get_device_properties(local_rank).multi_processor_count))
+        from powersystemsreliabilityassessment_amd import _lib as _rlib
+        code_hash = _rlib.code_object_sha256()
+        roof.update(counters_from_profile(args.workload, units_per_launch, torch.cuda.get_device_properties(local_rank).multi_processor_count,
+                                          kernel_ms_avg=avg_kernel_s * 1e3, code_hash=code_hash))
         out = {
             "metric": metric, "value": n_total / elapsed, "unit": unit, "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
             "ms_per_step": elapsed / args.steps * 1e3, "higher_is_better": True, "scaling": args.scaling,
@@ -294,6 +440,7 @@ def main():
                        "parallelism": f"scenario-index{' / year' if args.workload == 'seq' else ''} sharding x{world}, 1 all-reduce of relmc_acc per step "
                                       f"({comm.kind + ' through the C ABI' if comm is not None else 'torch.distributed ' + (pg_backend if world > 1 else '(single rank: no collective)')})"},
             "roofline": roof,
+            "binary": {"library": os.path.relpath(_rlib.LIB_PATH, ROOT), "code_object_sha256": code_hash, "version": _rlib.load().relmc_version().decode()},
             "comm": comm_info, "kernel_ms_per_rank": kernel_ms_per_rank,
             "indices": {"n": n_total, "edns_mw": total.sum_dns / n_total, "plc": total.n_fail / n_total,
                         "n_singular": int(total.n_singular), "n_nonconverged": int(total.n_nonconverged),
@@ -304,6 +451,12 @@ def main():
             out["indices"].update({"lole_h_per_yr": idx["lole"], "beta": idx["beta"]})
         if ttc_multi is not None:
             out["time_to_cov_1pct"] = ttc_multi
+        if db_multi is not None:
+            out["distinct_state_path"] = db_multi
+        out["launcher"] = "bench.py --gpus N (self-started ranks)" if os.environ.get("RELMC_BENCH_LAUNCHER") == "bench.py" else ("external (RANK / WORLD_SIZE from the environment)" if world > 1 else "none (single rank)")
+        if world > 1:
+            out["omitted"] = {"keys": ["cpu_baseline", "secondary", "sustained"] + (["time_to_cov_1pct", "distinct_state_path"] if args.workload != "nsq24" or args.no_time_to_cov else []),
+                              "why": "N > 1 lines are scaling rows: the CPU baseline, the other BASELINE configurations and the sustained-rate leg are measured on rank 0 at N = 1 only"}
         if world == 1 and args.workload == "nsq24" and not args.no_time_to_cov:
             # the reference checks beta every 100 samples (nsqMain.m:60, 299-312): the same spacing here (relmc_nsq_run evaluates stretches of
             # checkpoints per launch and stops at the reference's checkpoint), and a coarse spacing of 1e5 samples beside it
@@ -336,6 +489,8 @@ def main():
                 "time_to_cov_1pct_seconds": dt1, "samples": r1.current_iteration, "beta": r1.current_beta, "rows": r1.database_row_count,
                 "time_to_reference_beta_limit_0.0017": {"seconds": dt2, "samples": r2.current_iteration, "beta": r2.current_beta,
                                                         "rows": r2.database_row_count, "edns_mw": r2.accumulated_edns}}
+        if world == 1 and args.workload == "nsq24" and not args.no_sustained:
+            out["sustained"] = sustained_rate(eng, opts, args.seed, args.sustained_samples)
         if world == 1 and args.workload == "nsq24" and not args.no_secondary:
             out["secondary"] = secondary_workloads(eng, local_rank, opts, args.seed)
         if world == 1 and not args.no_cpu_baseline and args.workload == "nsq24":
@@ -349,9 +504,24 @@ def main():
         comm.close()
     if world > 1:
         dist.destroy_process_group()
-    if rdist.abandoned_threads():
+    if rdist.abandoned_threads() or rdist.kept_forever():
         sys.stdout.flush(); sys.stderr.flush()
         os._exit(0)              # a helper thread is still inside a stalled RCCL call: do not wait for it at interpreter exit
+
+
+def sustained_rate(eng, opts, seed, n):
+    """The headline's rate held over seconds, not over a 0.35 s burst: ONE relmc_nsq_accumulate call over `n` fresh scenarios (the index range
+    starts at 2^40, far from the timed steps), outside the timed region.  The library walks the range in launches of its own size; `kernel_ms_per_1e6`
+    is the HIP-event time of all of them per 1e6 scenarios, `value` the wall-clock rate of the call."""
+    import torch
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    acc = eng.nsq_accumulate(seed, 1 << 40, n, opts)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    return {"what": "one relmc_nsq_accumulate call, every sample solved, same kernel and options as the timed steps", "seconds": dt, "samples": int(acc.n),
+            "value": acc.n / dt, "unit": "scenarios/s", "kernel_ms_per_1e6": eng.last_kernel_ms() / (acc.n / 1e6),
+            "edns_mw": acc.sum_dns / acc.n, "mean_ipm_iterations": acc.sum_iters / acc.n, "n_nonconverged": int(acc.n_nonconverged)}
 
 
 def secondary_workloads(eng24, device, opts, seed, steps=3):
@@ -433,17 +603,19 @@ def sparse_flop_per_iteration(eng, case):
     return 43.0 * nblock + 29.0 * noff + 21.0 * case.nb + 14.0 * noff + 60.0 * case.nl + 70.0 * case.ninj + 30.0 * case.nb
 
 
-def counters_from_profile(workload, units_per_launch, n_cu):
+def counters_from_profile(workload, units_per_launch, n_cu, kernel_ms_avg=None, code_hash=None, profiles_dir=None):
     """Pipe utilisations and HBM traffic of the dominant kernel from the committed rocprofv3 PMC passes of this command
     (profiles/<current>/pmc_summary[_<workload>].json; separate --pmc runs, FETCH_SIZE doubled per MI355X_MICROARCH.md).
     SQ cycle counters tick once per 4 clocks per wavefront; GRBM_GUI_ACTIVE sums the 8 XCDs."""
     none = {"traffic": None, "lds_pipe_busy": None, "lds_conflict_frac": None, "valu_busy": None, "waves_per_simd": None,
-            "mfma_fp64_ops": None, "counters_source": "no committed profile for this workload"}
+            "mfma_fp64_ops": None, "counters_source": "no committed profile for this workload", "counters_stale": True,
+            "counters_stale_why": "no committed profile for this workload"}
+    pdir = profiles_dir or os.path.join(ROOT, "profiles")
     try:
-        with open(os.path.join(ROOT, "profiles", "current.txt")) as fh:
+        with open(os.path.join(pdir, "current.txt")) as fh:
             name = fh.read().strip()
         fn = "pmc_summary.json" if workload == "nsq24" else f"pmc_summary_{workload}.json"
-        with open(os.path.join(ROOT, "profiles", name, fn)) as fh:
+        with open(os.path.join(pdir, name, fn)) as fh:
             summ = json.load(fh)
     except (OSError, ValueError):
         return none
@@ -468,6 +640,22 @@ def counters_from_profile(workload, units_per_launch, n_cu):
         res["traffic"] = t["bytes_per_scenario"] * units_per_launch if t else None
         res["traffic_unit"] = "bytes per launch (HBM, PMC FETCH_SIZE x2 + WRITE_SIZE)"
         res["counters_source"] = f"from_profile: profiles/{name}/{fn} (rocprofv3 --pmc passes of `bench.py --workload {workload} --steps 1 --warmup 0`, not measured in this run)"
+        # is the profile about THIS binary, and does the kernel still take the time it took under the profiler?  (scripts/summarize_profile.py
+        # records the code-object hash the profiled bench line printed and the minimum launch duration of the kernel trace)
+        why = []
+        ph, pmin = summ.get("code_object_sha256"), summ.get("kernel_ms_min")
+        res["profile_code_object_sha256"], res["profile_kernel_ms_min"] = ph, pmin
+        if not ph:
+            why.append("the profile summary records no code-object hash")
+        elif code_hash is not None and ph != code_hash:
+            why.append(f"profiled code object {ph[:12]} != this library's {code_hash[:12]}")
+        if pmin and kernel_ms_avg is not None:
+            pmin_l = pmin * units_per_launch / max(1, summ.get("units_per_traced_launch", units_per_launch))
+            if abs(kernel_ms_avg - pmin_l) > 0.03 * pmin_l:
+                why.append(f"kernel_ms_avg {kernel_ms_avg:.3f} is more than 3 % off the profile's minimum launch {pmin_l:.3f} ms")
+        res["counters_stale"] = bool(why)
+        if why:
+            res["counters_stale_why"] = "; ".join(why)
         return res
     except (KeyError, ZeroDivisionError, TypeError):
         return none

@@ -346,7 +346,7 @@ typedef struct {
     int64_t years_cap;
     relmc_seq_year* results_year;   /* results_year.ens / dlc / nlc (+ contingency hours), seqMain.m:162-176 */
     double* cum_eens;               /* results_cum.eens, :180 */
-    double* cum_cov;                /* results_cum.cov, :183-185 (entry 0 = 0 as in the reference) */
+    double* cum_cov;                /* results_cum.cov, :183-185 (entry 0 = 0 as in the reference; NaN = 0/0 while no year has had curtailment, as :184) */
 } relmc_seq_opts;
 typedef struct {
     int32_t final_year;       /* years simulated = the stopping year (seqMain.m:203) */

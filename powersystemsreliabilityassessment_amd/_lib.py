@@ -42,6 +42,33 @@ def build(verbose: bool = False) -> str:
     return LIB_PATH
 
 
+def code_object_sha256(path: str | None = None) -> str:
+    """sha256 of the device code a library carries: the bytes of its `.hip_fatbin` ELF section (the clang offload bundles of every unit,
+    i.e. the gfx950 code objects; host code is not part of it).  bench.py prints it and the committed profile summaries record it, so a line
+    can tell whether the counters it quotes were measured on the binary that ran (scripts/summarize_profile.py)."""
+    import hashlib
+    import struct
+    path = path or LIB_PATH
+    with open(path, "rb") as fh:
+        b = fh.read()
+    if b[:4] != b"\x7fELF" or b[4] != 2 or b[5] != 1:
+        raise RelmcLibraryError(f"{path}: not a little-endian ELF64 file")
+    shoff, = struct.unpack_from("<Q", b, 0x28)
+    shentsize, shnum, shstrndx = struct.unpack_from("<HHH", b, 0x3A)
+    sec = lambda i: struct.unpack_from("<IIQQQQIIQQ", b, shoff + i * shentsize)       # name, type, flags, addr, offset, size, ...
+    str_off = sec(shstrndx)[4]
+    h = hashlib.sha256()
+    found = False
+    for i in range(shnum):
+        nm, _, _, _, off, size = sec(i)[:6]
+        name = b[str_off + nm:b.index(b"\0", str_off + nm)]
+        if name == b".hip_fatbin":
+            h.update(b[off:off + size]); found = True
+    if not found:
+        raise RelmcLibraryError(f"{path}: no .hip_fatbin section (not a HIP library)")
+    return h.hexdigest()
+
+
 _lib = None
 
 

@@ -8,6 +8,7 @@
 #include <cstdio>
 #include <cstdlib>
 #include <cstring>
+#include <cstddef>
 #include <mutex>
 #include <thread>
 
@@ -33,9 +34,10 @@ struct RcclApi {
     int (*CommUserRank)(void*, int*) = nullptr;
 };
 RcclApi g_rccl;
-const char* rccl_load()
+std::once_flag g_rccl_once;
+const char* g_rccl_err = nullptr;
+const char* rccl_load_once()
 {
-    if (g_rccl.h) return nullptr;
     for (const char* name : {"librccl.so.1", "librccl.so", "/opt/rocm/lib/librccl.so.1"}) {
         g_rccl.h = dlopen(name, RTLD_NOW | RTLD_GLOBAL);
         if (g_rccl.h) break;
@@ -51,10 +53,16 @@ const char* rccl_load()
     g_rccl.CommCount = reinterpret_cast<int (*)(void*, int*)>(dlsym(g_rccl.h, "ncclCommCount"));
     g_rccl.CommUserRank = reinterpret_cast<int (*)(void*, int*)>(dlsym(g_rccl.h, "ncclCommUserRank"));
     if (!g_rccl.GetUniqueId || !g_rccl.CommInitRank || !g_rccl.AllReduce || !g_rccl.CommDestroy || !g_rccl.GroupStart || !g_rccl.GroupEnd) {
-        g_rccl.h = nullptr;
         return "relmc_comm: librccl.so lacks the expected entry points";
     }
     return nullptr;
+}
+// the table is filled exactly once per process, whichever context / host thread asks first (two contexts on two threads are a supported
+// use of the ABI: tests/c/abi_smoke.c); a failed load stays failed with its reason
+const char* rccl_load()
+{
+    std::call_once(g_rccl_once, []() { g_rccl_err = rccl_load_once(); });
+    return g_rccl_err;
 }
 
 int rccl_fail(relmc_ctx* ctx, const char* what, int rc)
@@ -88,6 +96,7 @@ struct Watchdog {
         }
     }
 };
+// (per context: a context is driven by one host thread at a time -- include/relmc.h -- so its watchdog needs no lock of its own)
 Watchdog* watchdog_of(relmc_ctx* ctx)
 {
     if (!ctx->watchdog) {
@@ -147,6 +156,10 @@ int comm_allreduce_f64(relmc_ctx* ctx, double* buf, int64_t count)
     if (ctx->host_allreduce) {
         // through the host's relmc_acc all-reduce, 130 doubles per call (sum_dns, sum_dns2, sum_nodal): the integers ride along as zeros
         constexpr int64_t kPer = 2 + RELMC_MAX_BUS;
+        static_assert(offsetof(relmc_acc, sum_dns2) == offsetof(relmc_acc, sum_dns) + sizeof(double) &&
+                      offsetof(relmc_acc, sum_nodal) == offsetof(relmc_acc, sum_dns) + 2 * sizeof(double) &&
+                      sizeof(((relmc_acc*)nullptr)->sum_nodal) == sizeof(double) * RELMC_MAX_BUS,
+                      "comm_allreduce_f64 carries 2 + RELMC_MAX_BUS doubles through the contiguous members sum_dns, sum_dns2, sum_nodal of relmc_acc");
         relmc_acc box;
         for (int64_t done = 0; done < count; done += kPer) {
             const int64_t m = (count - done) < kPer ? (count - done) : kPer;

@@ -229,6 +229,9 @@ int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* o, relmc_seq_result*
         const int64_t m = (o->max_years - done) < batch ? (o->max_years - done) : batch;
         const int64_t lo = done + m * r / R, cnt = done + m * (r + 1) / R - lo;
         relmc_acc acc;
+        // what a batch that is cut at the stopping year and taken again must not count twice (as relmc_nsq_run): second attempts, kernel time
+        const int64_t ru0 = ctx->retry_units, rcv0 = ctx->retry_converged, rd0 = ctx->retry_dense_units, rdc0 = ctx->retry_dense_converged, ro0 = ctx->retry_overflow;
+        const double kernel_ms0 = kernel_ms;
         int rc = eval(lo, cnt, &acc);
         const std::string local_err = ctx->err;
         // annual triples of the batch in year order on every rank; a rank whose years failed says so with NaNs every rank will see
@@ -255,7 +258,7 @@ int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* o, relmc_seq_result*
             if (y > 1) {                                                                // :183-185, std = sample standard deviation
                 double ss = 0.0; for (double v : ens) ss += (v - mean) * (v - mean);
                 const double sd = std::sqrt(ss / (double)(y - 1));
-                cov = mean > 0.0 ? sd / (mean * std::sqrt((double)y)) : 0.0;
+                cov = sd / (mean * std::sqrt((double)y));                               // all years so far without curtailment: 0 / 0 = NaN, as the reference (:184)
             }
             if (o->results_year) { relmc_seq_year& Y = o->results_year[y - 1]; Y.ens = ens.back(); Y.dlc = dlc.back(); Y.nlc = nlc.back(); Y.n_contingency = (int64_t)trip[(size_t)(4 * k + 3)]; }
             if (o->cum_eens) o->cum_eens[y - 1] = mean;
@@ -267,6 +270,9 @@ int32_t relmc_seq_run(relmc_ctx* ctx, const relmc_seq_opts* o, relmc_seq_result*
             // the reference stops inside this batch: its accumulators (seqMain.m:146-159) hold the years up to the stopping year only
             const int64_t hi = done + used;
             const int64_t cnt2 = (lo + cnt < hi ? lo + cnt : hi) - lo;
+            // the discarded pass leaves no trace in the bookkeeping: kernel_seconds and relmc_retry_stats do not depend on batch_years
+            ctx->retry_units = ru0; ctx->retry_converged = rcv0; ctx->retry_dense_units = rd0; ctx->retry_dense_converged = rdc0; ctx->retry_overflow = ro0;
+            kernel_ms = kernel_ms0;
             rc = eval(lo, cnt2 > 0 ? cnt2 : 0, &acc);
         }
         if (R > 1) {

@@ -72,6 +72,19 @@ def abandoned_threads() -> int:
     return len(_ABANDONED)
 
 
+_KEPT = []               # (communicator, engine) pairs that must never be finalised: a peer is (or may be) stuck inside RCCL on that communicator
+
+
+def keep_forever(*objs) -> None:
+    """Pin objects for the life of the process: dropping the last reference to an Engine runs relmc_ctx_destroy -> ncclCommDestroy, which
+    can hang when a peer of that communicator stalled.  A process that called this leaves through os._exit (no finalisers)."""
+    _KEPT.append(objs)
+
+
+def kept_forever() -> int:
+    return len(_KEPT)
+
+
 class NativeComm:
     """The library's own RCCL communicator (relmc_comm_*, include/relmc.h): what a Julia / C host would use.  Only the 128-byte
     unique id is exchanged through the host's rendezvous (`_broadcast_bytes`); the process needs no torch `nccl` group beside it
@@ -335,7 +348,8 @@ def seq_run_distributed(years_fn, *, seed: int = 1, cov_threshold: float = 0.05,
             years = np.vstack([years, batch[k:k + 1]])
             y = years.shape[0]
             mean = float(years[:, 0].mean())
-            cov = float(years[:, 0].std(ddof=1) / (mean * np.sqrt(y))) if y > 1 and mean > 0 else 0.0
+            with np.errstate(invalid="ignore", divide="ignore"):                     # no curtailment yet: 0 / 0 = NaN, as seqMain.m:184
+                cov = float(np.float64(years[:, 0].std(ddof=1)) / (mean * np.sqrt(y))) if y > 1 else 0.0
             cum_eens.append(mean); cum_cov.append(cov)
             if y > 1 and 0 < cov < cov_threshold:
                 stop, used = True, k + 1

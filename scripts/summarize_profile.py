@@ -54,5 +54,31 @@ for lg in ("trace_bench.log", "pmc_sq.log"):
                 "note": "rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in separate passes over `bench.py --steps 1 --warmup 0 --no-time-to-cov` (one 1e6-scenario launch); units KiB; FETCH_SIZE "
                         "doubled per MI355X_MICROARCH.md (gfx950 reports half of wide reads), WRITE_SIZE uncalibrated",
                 "fetch_kib": fk, "write_kib": wk, "scenarios": scen, "bytes_per_scenario": b / scen, "bytes_per_1e6_scenario_launch": b / scen * 1e6}
+# what ties the summary to a binary and to a launch duration (bench.py sets roofline.counters_stale from these): the code-object hash the
+# PROFILED bench line printed about the library it ran, and the shortest launch of the production kernel in the kernel trace (the average
+# of a handful of launches carries the cold first one)
+hashes = set()
+for lg in ("trace_bench.log", "pmc_sq.log", "pmc_lds.log", "pmc_fetch.log", "pmc_write.log"):
+    try:
+        for ln in open(os.path.join(src, lg)):
+            if ln.startswith("{") and '"metric"' in ln:
+                j = json.loads(ln)
+                if "binary" in j:
+                    hashes.add(j["binary"]["code_object_sha256"])
+                if lg == "trace_bench.log":
+                    summary["units_per_traced_launch"] = j["roofline"]["units_per_launch"]
+    except OSError:
+        pass
+if len(hashes) == 1:
+    summary["code_object_sha256"] = hashes.pop()
+elif hashes:
+    summary["code_object_sha256_conflict"] = sorted(hashes)       # the passes ran different binaries: no hash, the line will say stale
+if stats:
+    rows = [r for r in csv.DictReader(open(stats[0])) if "eval_kernel" in r["Name"]]
+    if rows:
+        top = max(rows, key=lambda r: float(r["TotalDurationNs"]))
+        summary["kernel_ms_min"] = float(top["MinNs"]) * 1e-6
+        summary["kernel_ms_avg_traced"] = float(top["AverageNs"]) * 1e-6
+        summary["kernel_traced"] = top["Name"].split("(")[0]
 json.dump(summary, open(os.path.join(dst, f"pmc_summary{sfx}.json"), "w"), indent=1)
 print("wrote", dst, sorted(os.listdir(dst)))

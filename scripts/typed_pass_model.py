@@ -6,12 +6,20 @@ from relmc_debug_symbolic's pass program (full-form equivalents of every task), 
 pure (R / G) or mixed, choosing per pass whichever candidate set maximises (tasks done) / (instructions spent), then applies the same
 half / quarter forms to sparsely filled passes.  Output: passes and LDS instructions of the update phase, shipped against typed."""
 import os, sys
-sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+# The shipped librelmc.so reads no RELMC_* ablation variable: RELMC_NO_QUARTER exists only in the -DRELMC_DEV_SWITCHES build
+# (make -C powersystemsreliabilityassessment_amd/csrc ablate/librelmc_dev.so).  Without it the dump holds half- and quarter-form passes
+# and this model would read them as full-form tasks: refuse instead of printing a wrong number.
+DEV = os.path.join(ROOT, "powersystemsreliabilityassessment_amd", "csrc", "ablate", "librelmc_dev.so")
+if not os.environ.get("RELMC_LIB_PATH"):
+    if not os.path.exists(DEV):
+        sys.exit(f"typed_pass_model.py needs the dev-switch build: {DEV} is missing (make -C powersystemsreliabilityassessment_amd/csrc ablate/librelmc_dev.so)")
+    os.environ["RELMC_LIB_PATH"] = DEV
+os.environ["RELMC_NO_QUARTER"] = "1"        # the dump then holds every update task in full form
 import numpy as np
 from powersystemsreliabilityassessment_amd import case24, case96
 from tests import schedule_interp as si
-
-os.environ["RELMC_NO_QUARTER"] = "1"        # the dump then holds every update task in full form
 
 
 def tasks_of(case):

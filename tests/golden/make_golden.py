@@ -314,6 +314,32 @@ def rts96_numfail_fixture(scan_json):
     print("rts96_numfail_fixture.json:", len(lists), "states; C oracle == numpy MIPS status on", agree, "of", 2 * len(lists))
 
 
+def rts96_numfail_device(device_json):
+    """Adds what the device's PRODUCTION entry point returns for the numfail states (tests/tools/numfail96_device.py on the GPU box: status and
+    iteration count after the further elimination orders / the dense solve) to rts96_numfail_fixture.json as `device_retried`, together with the
+    distance of that count to the C oracle's: the GPU parity test asserts both per state."""
+    path = os.path.join(HERE, "rts96_numfail_fixture.json")
+    with open(path) as f:
+        fx = json.load(f)
+    with open(device_json) as f:
+        dev = json.load(f)
+    assert dev["n_states"] == len(fx["states"])
+    fx["device_retried_from"] = dict(code_object_sha256=dev["code_object_sha256"], version=dev["version"],
+                                     how="tests/tools/numfail96_device.py on an MI355X, merged by make_golden.py --numfail96-device")
+    for name in ("emulate", "physical"):
+        for i, e in enumerate(fx["states"]):
+            it, stt = dev[name]["iters"][i], dev[name]["status"][i]
+            co = e[name]["c_oracle"]
+            e[name]["device_retried"] = dict(status=stt, iters=it, dns=dev[name]["dns"][i],
+                                             iters_minus_c_oracle=(it - co["iters"]) if (co and co["status"] == 0 and stt == 0) else None)
+    with open(path, "w") as f:
+        json.dump(fx, f)
+    gaps = [e[n]["device_retried"]["iters_minus_c_oracle"] for e in fx["states"] for n in ("emulate", "physical")]
+    gaps = [g for g in gaps if g is not None]
+    print("rts96_numfail_fixture.json: device_retried recorded for", len(fx["states"]), "states x 2 policies; iteration gaps to the C oracle:",
+          {g: gaps.count(g) for g in sorted(set(gaps))})
+
+
 if __name__ == "__main__":
     ap = argparse.ArgumentParser()
     ap.add_argument("--reference", default="/root/reference")
@@ -323,7 +349,11 @@ if __name__ == "__main__":
     ap.add_argument("--only-rts96", action="store_true")
     ap.add_argument("--only-layout", action="store_true", help="export_layout.json alone (file layouts of the reference's exports)")
     ap.add_argument("--numfail96", default="", help="scan JSON of tests/tools/numfail96.py -> rts96_numfail_fixture.json")
+    ap.add_argument("--numfail96-device", default="", help="JSON of tests/tools/numfail96_device.py -> `device_retried` entries of rts96_numfail_fixture.json")
     a = ap.parse_args()
+    if a.numfail96_device:
+        rts96_numfail_device(a.numfail96_device)
+        sys.exit(0)
     if a.numfail96:
         rts96_numfail_fixture(a.numfail96)
         sys.exit(0)

@@ -251,6 +251,133 @@ def test_watchdog_turns_a_stuck_peer_into_a_diagnosis(tmp_path):
         p1.kill(); p1.wait()
 
 
+_FAKE_RANK = """
+import os, sys, time
+r, w = int(os.environ["RANK"]), int(os.environ["WORLD_SIZE"])
+assert os.environ["LOCAL_RANK"] == str(r) and os.environ["MASTER_ADDR"] == "127.0.0.1" and int(os.environ["MASTER_PORT"]) > 0
+assert "torch" not in sys.modules
+print(f"rank {r} of {w} args {sys.argv[1:]}", flush=True)
+mode = sys.argv[1]
+if mode == "ok":
+    sys.exit(0)
+if mode == "one_fails":          # rank 1 leaves with the watchdog's code at once; the others would sit for a minute
+    if r == 1:
+        sys.exit(86)
+    time.sleep(60)
+"""
+
+
+def test_bench_gpus_flag_starts_the_ranks_itself(tmp_path):
+    """`python bench.py --gpus N` with no launcher around it IS the launcher (the flag was parsed and never read, so the plain
+    command measured one GPU and said n_gpus 1).  The parent must not import torch, must hand every rank RANK / LOCAL_RANK / WORLD_SIZE /
+    MASTER_ADDR / MASTER_PORT and the same arguments, relay only rank 0's stdout, and end with the first failing rank's code after
+    stopping the rest by pid; a launcher whose WORLD_SIZE disagrees with --gpus is refused before anything is imported."""
+    import importlib.util
+    import time
+    spec = importlib.util.spec_from_file_location("bench_mod", os.path.join(ROOT, "bench.py"))
+    fake = tmp_path / "fake_rank.py"
+    fake.write_text(_FAKE_RANK)
+    drv = tmp_path / "drv.py"
+    drv.write_text(f"import sys, importlib.util\nspec = importlib.util.spec_from_file_location('bench_mod', {os.path.join(ROOT, 'bench.py')!r})\n"
+                   f"m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)\n"
+                   f"rc = m.launch_ranks(int(sys.argv[1]), sys.argv[2:], script={str(fake)!r})\nassert 'torch' not in sys.modules\nsys.exit(rc)\n")
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK")}
+    ok = subprocess.run([sys.executable, str(drv), "8", "ok", "--steps", "2"], capture_output=True, text=True, timeout=120, env=env)
+    assert ok.returncode == 0, ok.stderr[-800:]
+    assert ok.stdout.strip() == "rank 0 of 8 args ['ok', '--steps', '2']"                    # rank 0's stdout only
+    assert all(f"rank {r} of 8" in ok.stderr for r in range(1, 8))                           # the other ranks' stdout lands on stderr
+    t0 = time.time()
+    bad = subprocess.run([sys.executable, str(drv), "4", "one_fails"], capture_output=True, text=True, timeout=120, env=env)
+    assert bad.returncode == 86 and time.time() - t0 < 30, (bad.returncode, bad.stderr[-800:])
+    assert "rank 1 of 4" in bad.stderr and "left with code 86: stopping the other ranks" in bad.stderr
+    # a launcher that disagrees with --gpus: refused with both numbers, before torch is imported (fast)
+    t0 = time.time()
+    mis = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "8"], capture_output=True, text=True, timeout=60,
+                         env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert mis.returncode == 7 and "WORLD_SIZE=2" in mis.stderr and "--gpus says 8" in mis.stderr and mis.stdout == ""
+    mis1 = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "1"], capture_output=True, text=True, timeout=60,
+                          env=dict(env, RANK="0", WORLD_SIZE="2", LOCAL_RANK="0"))
+    assert mis1.returncode == 7
+    # no GPU here: the plain command starts its two ranks, both refuse loudly, the parent reports the code (never a silent CPU path)
+    import torch
+    if not torch.cuda.is_available():
+        nog = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--gpus", "2", "--steps", "1", "--warmup", "0"], capture_output=True, text=True,
+                             timeout=300, env=env)
+        assert nog.returncode != 0 and "needs a GPU" in nog.stderr and "stopping the other ranks" in nog.stderr and '"metric"' not in nog.stdout
+
+
+def _plain_bench(tmp_path, tag, extra, expect_ok=True, timeout=900):
+    """bench.py called the way the driver calls it: no external launcher."""
+    import json
+    f = tmp_path / f"acc_{tag}.json"
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "WORLD_SIZE", "LOCAL_RANK", "MASTER_PORT")}
+    out = subprocess.run([sys.executable, os.path.join(ROOT, "bench.py"), "--no-cpu-baseline", "--dump-acc", str(f)] + extra,
+                         capture_output=True, text=True, timeout=timeout, env=env)
+    if not expect_ok:
+        return out
+    assert out.returncode == 0, out.stderr[-3000:]
+    line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln]
+    assert len(line) == 1, out.stdout[-2000:]
+    return json.loads(line[0]), json.load(open(f))
+
+
+def _same_acc(a, b):
+    assert a["ints"] == b["ints"]
+    np.testing.assert_allclose([float.fromhex(x) for x in a["dbls"]], [float.fromhex(x) for x in b["dbls"]], rtol=1e-11, atol=1e-9)
+
+
+@pytest.mark.gpu
+def test_plain_bench_command_runs_two_ranks(tmp_path):
+    """`python bench.py --gpus 2 ...` with NO external launcher: two ranks (here on the one GPU of the box, host collective), n_gpus 2, the
+    communicator itself reports 2 ranks, and the merged accumulators equal the 1-rank run over the same global scenario range.  Asking for
+    more GPUs than the node has, without --share-device, is refused with both numbers."""
+    j2, a2 = _plain_bench(tmp_path, "p2", ["--gpus", "2", "--share-device", "--comm", "host", "--steps", "2", "--warmup", "1", "--batch", "50000"])
+    j1, a1 = _plain_bench(tmp_path, "p1", ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "100000", "--no-time-to-cov", "--no-secondary"])
+    assert j2["n_gpus"] == 2 and j2["comm"]["nranks_seen"] == 2 and j2["comm"]["backend"] == "host-collective" and len(j2["comm"]["devices"]) == 2
+    assert j2["launcher"].startswith("bench.py --gpus N") and j1["launcher"].startswith("none") and j1["n_gpus"] == 1
+    assert j2["indices"]["n"] == j1["indices"]["n"] == 200000
+    _same_acc(a2, a1)
+    assert set(j2["omitted"]["keys"]) >= {"cpu_baseline", "secondary", "sustained"} and "omitted" not in j1
+    ttc = j2["time_to_cov_1pct"]
+    assert "relmc_nsq_run" in ttc["loop"] and ttc["beta"] < 0.01 and ttc["batch"] == 65536 and ttc["samples"] % 65536 == 0
+    db = j2["distinct_state_path"]
+    assert db["per_rank_database"] is True and len(db["rows_per_rank"]) == 2 and db["beta"] < 0.0017
+    assert 1.0 <= db["redundant_solves_x"] <= 2.0 and max(db["rows_per_rank"]) <= db["rows_single_database"] <= sum(db["rows_per_rank"])
+    import torch
+    if torch.cuda.device_count() < 3:
+        bad = _plain_bench(tmp_path, "p3", ["--gpus", "3", "--steps", "1", "--warmup", "0"], expect_ok=False)
+        assert bad.returncode == 6 and "--gpus 3 but this node has" in bad.stderr and '"metric"' not in bad.stdout
+
+
+@pytest.mark.gpu
+def test_plain_bench_command_eight_rank_rehearsal(tmp_path):
+    """BASELINE configs[2] / [3] / [4] are 8-GPU shapes and no 8-GPU node has ever run them: rehearse the plain command with EIGHT ranks
+    sharing the one GPU (host collective).  Weak scaling with the time-to-CoV loop at 32 768 x 8 samples per check, strong scaling over a
+    fixed 8e6-sample step, and the sequential workload over 8 x 2 years: eight PCI ids gathered, eight ranks in the communicator's own
+    count, accumulators equal to ONE rank over the same global range (integers exactly)."""
+    w8, aw8 = _plain_bench(tmp_path, "w8", ["--gpus", "8", "--share-device", "--comm", "host", "--steps", "2", "--warmup", "1", "--batch", "25000"])
+    w1, aw1 = _plain_bench(tmp_path, "w1", ["--gpus", "1", "--steps", "2", "--warmup", "1", "--batch", "200000", "--no-time-to-cov", "--no-secondary"])
+    assert w8["n_gpus"] == 8 and w8["comm"]["nranks_seen"] == 8 and len(w8["comm"]["devices"]) == 8 and len(set(w8["comm"]["devices"])) == 1
+    assert len(w8["kernel_ms_per_rank"]) == 8 and min(w8["kernel_ms_per_rank"]) > 0
+    assert w8["indices"]["n"] == w1["indices"]["n"] == 400000
+    _same_acc(aw8, aw1)
+    ttc = w8["time_to_cov_1pct"]
+    assert ttc["batch"] == 32768 * 8 and ttc["samples"] % (32768 * 8) == 0 and ttc["beta"] < 0.01 and "relmc_nsq_run" in ttc["loop"]
+    db = w8["distinct_state_path"]
+    assert len(db["rows_per_rank"]) == 8 and 1.0 <= db["redundant_solves_x"] <= 8.0
+    s8, as8 = _plain_bench(tmp_path, "s8", ["--gpus", "8", "--share-device", "--comm", "host", "--steps", "1", "--warmup", "0", "--scaling", "strong", "--total", "8000000",
+                                            "--no-time-to-cov"])
+    s1, as1 = _plain_bench(tmp_path, "s1", ["--gpus", "1", "--steps", "1", "--warmup", "0", "--scaling", "strong", "--total", "8000000", "--no-time-to-cov", "--no-secondary"])
+    assert s8["scaling"] == "strong" and s8["n_gpus"] == 8 and s8["indices"]["n"] == s1["indices"]["n"] == 8000000
+    _same_acc(as8, as1)
+    q8, aq8 = _plain_bench(tmp_path, "q8", ["--gpus", "8", "--share-device", "--comm", "host", "--workload", "seq", "--years", "2", "--steps", "1", "--warmup", "0"])
+    q1, aq1 = _plain_bench(tmp_path, "q1", ["--gpus", "1", "--workload", "seq", "--years", "16", "--steps", "1", "--warmup", "0"])
+    assert q8["n_gpus"] == 8 and q8["comm"]["nranks_seen"] == 8 and q8["indices"]["n"] == q1["indices"]["n"] > 0
+    _same_acc(aq8, aq1)
+    print(f"8-rank rehearsal on one GPU: weak {w8['value']:.3g}/s, strong {s8['value']:.3g}/s, seq {q8['value']:.3g} hourly OPFs/s; "
+          f"database redundancy x{db['redundant_solves_x']:.2f}")
+
+
 @pytest.mark.gpu
 def test_bench_two_ranks_share_device(tmp_path):
     """bench.py's N > 1 path (torch.distributed launcher, one all-reduce per step) with two ranks on the one GPU of the box
@@ -392,6 +519,53 @@ def test_bench_counter_fields_come_from_the_committed_profile():
         assert 0.3 < c["lds_pipe_busy"] < 0.9 and 0.3 < c["valu_busy"] < 0.9 and 0.1 < c["lds_conflict_frac"] < 0.6
         assert c["waves_per_simd"] == 2.0 and c["mfma_fp64_ops"] == 0.0 and c["traffic"] > 0
     assert bench.dense_flop_per_iter(24) == pytest.approx(40525.67, rel=1e-6)          # order 47
+
+
+def test_bench_says_when_the_quoted_counters_are_not_about_this_binary(tmp_path):
+    """The roofline's pipe counters are copied from a committed profile (a program cannot read its own PMCs): the line must tell when that
+    profile was taken on ANOTHER binary or when the kernel no longer takes the profiled time.  The summary records the code-object hash of the
+    profiled library (sha256 of its .hip_fatbin) and the minimum traced launch; one flipped hex digit, a drifted kernel time, or a summary
+    without a hash each set roofline.counters_stale."""
+    import json
+    import shutil
+    import bench
+    h = _lib.code_object_sha256()
+    assert re.fullmatch(r"[0-9a-f]{64}", h) and h == _lib.code_object_sha256(_lib.LIB_PATH)
+    other = tmp_path / "other.so"                          # the hash covers the device code: one changed byte inside .hip_fatbin changes it
+    blob = bytearray(open(_lib.LIB_PATH, "rb").read())
+    at = blob.index(b"__CLANG_OFFLOAD_BUNDLE__") if b"__CLANG_OFFLOAD_BUNDLE__" in blob else blob.index(b"CCOB")
+    blob[at + 64] ^= 1
+    other.write_bytes(bytes(blob))
+    assert _lib.code_object_sha256(str(other)) != h
+    with pytest.raises(_lib.RelmcLibraryError):
+        _lib.code_object_sha256(os.path.join(ROOT, "oracle", "librelmc_oracle.so"))       # a CPU library carries no device code
+    cur = open(os.path.join(ROOT, "profiles", "current.txt")).read().strip()
+    pd = tmp_path / "profiles"
+    (pd / cur).mkdir(parents=True)
+    (pd / "current.txt").write_text(cur)
+    summ = json.load(open(os.path.join(ROOT, "profiles", cur, "pmc_summary.json")))
+    def counters(ms, **edit):
+        d = dict(summ, code_object_sha256=h, kernel_ms_min=17.40, units_per_traced_launch=1_000_000)
+        d.update(edit)
+        d = {k: v for k, v in d.items() if v is not None}
+        json.dump(d, open(pd / cur / "pmc_summary.json", "w"))
+        return bench.counters_from_profile("nsq24", 1_000_000, 256, kernel_ms_avg=ms, code_hash=h, profiles_dir=str(pd))
+    ok = counters(17.45)
+    assert ok["counters_stale"] is False and "counters_stale_why" not in ok and ok["profile_code_object_sha256"] == h and ok["profile_kernel_ms_min"] == 17.40
+    flipped = h[:-1] + ("0" if h[-1] != "0" else "1")
+    bad = counters(17.45, code_object_sha256=flipped)
+    assert bad["counters_stale"] is True and "!= this library's" in bad["counters_stale_why"]
+    slow = counters(18.2)
+    assert slow["counters_stale"] is True and "more than 3 %" in slow["counters_stale_why"]
+    assert counters(17.45, units_per_traced_launch=2_000_000)["counters_stale"] is True      # the minimum is scaled to the launch size
+    assert counters(8.70, units_per_traced_launch=2_000_000)["counters_stale"] is False
+    nohash = counters(17.45, code_object_sha256=None)
+    assert nohash["counters_stale"] is True and "no code-object hash" in nohash["counters_stale_why"]
+    assert bench.counters_from_profile("nsq24", 1_000_000, 256, profiles_dir=str(tmp_path / "nothing"))["counters_stale"] is True
+    # the committed summaries of the current profile carry the hash of a library (this one, as long as the device code is unchanged)
+    for fn in ("pmc_summary.json", "pmc_summary_rts96.json", "pmc_summary_seq.json"):
+        d = json.load(open(os.path.join(ROOT, "profiles", cur, fn)))
+        assert re.fullmatch(r"[0-9a-f]{64}", d.get("code_object_sha256", "")) and d["kernel_ms_min"] > 0, fn
 
 
 # ---- exports (nsqMain.m:398-405, seqMain.m:255-262): the files the reference leaves behind, same names and layout ------------------

@@ -201,15 +201,17 @@ def test_gpu96_with_the_ties_out_is_three_rts24_systems(engine96, engine, case96
 
 
 @pytest.mark.gpu
-def test_gpu96_sampled_state_contract_5e4(engine96, oracle96):
-    """The numerical contract on SAMPLED RTS-96 states (the first 5e4 samples of seed 1, device against the C oracle, state by state):
-    status identical, |dns difference| <= 1e-6 MW, iteration counts equal but for +-1 on fewer than 0.1 % of the states, per-bus nodal sums
-    to 2 % (round 3 kept this as a builder-run log over 2e5 samples: 0 / 0 / 0.0135 %, profiles/r3_final/sampled_vs_oracle_rts96.log)."""
+@pytest.mark.parametrize("policy", [_abi.RELMC_REFERENCE_EMULATE, _abi.RELMC_PHYSICAL], ids=["emulate", "physical"])
+def test_gpu96_sampled_state_contract_5e4(engine96, oracle96, policy):
+    """The numerical contract on SAMPLED RTS-96 states (the first 5e4 samples of seed 1, device against the C oracle, state by state), under
+    BOTH policies (round 4 ran REFERENCE_EMULATE only): status identical, |dns difference| <= 1e-6 MW, iteration counts equal but for +-1 on
+    fewer than 0.1 % of the states, per-bus nodal sums to 2 % (round 3 kept this as a builder-run log over 2e5 samples: 0 / 0 / 0.0135 %,
+    profiles/r3_final/sampled_vs_oracle_rts96.log)."""
     from powersystemsreliabilityassessment_amd import api
     n = 50_000
     st = engine96.mc_sampling(None, n, seed=1, first_index=0)
-    dns, nodal, info = engine96.mc_simulation(st, mpopt=api.mpoption(_abi.RELMC_REFERENCE_EMULATE), return_info=True)
-    ref = oracle96.mc_simulation(st, _abi.RELMC_REFERENCE_EMULATE, nthreads=16)
+    dns, nodal, info = engine96.mc_simulation(st, mpopt=api.mpoption(policy), return_info=True)
+    ref = oracle96.mc_simulation(st, policy, nthreads=16)
     np.testing.assert_array_equal(info["status"], ref["status"])
     assert np.abs(dns - ref["dns"]).max() <= 1e-6
     di = np.abs(info["iters"] - ref["iters"])
@@ -331,8 +333,18 @@ def test_gpu96_numfail_states_vs_oracle(engine96, oracle96, numfail96):
         dev_ok, orc_ok = info["status"] == 0, r["status"] == 0
         assert dev_ok.sum() >= N - 1 and (dev_ok & orc_ok).sum() >= orc_ok.sum() - 1
         both = dev_ok & orc_ok
-        # heavy-outage states solved under the further orders: the iteration counts agree on most and differ by a few on the rest (recorded: 6 at most)
-        assert np.abs(info["iters"][both] - r["iters"][both]).max() <= 8 and (info["iters"][both] == r["iters"][both]).mean() > 0.75
+        # heavy-outage states solved under the further orders: the fixture records, per state, the status and iteration count the device's
+        # production entry point returned when it was generated (tests/tools/numfail96_device.py) and its distance to the C oracle's count
+        # (make_golden.py --numfail96-device): exactly those, state by state -- a static schedule is deterministic
+        gaps = []
+        for i, x in enumerate(numfail96["states"]):
+            rec = x[name]["device_retried"]
+            assert (int(info["status"][i]), int(info["iters"][i])) == (rec["status"], rec["iters"]), (name, i, info["status"][i], info["iters"][i], rec)
+            if both[i]:
+                assert rec["iters_minus_c_oracle"] is not None and int(info["iters"][i]) - int(r["iters"][i]) == rec["iters_minus_c_oracle"], (name, i)
+                gaps.append(rec["iters_minus_c_oracle"])
+        assert max(abs(g) for g in gaps) <= 8 and np.mean([g == 0 for g in gaps]) > 0.75             # what the recorded gaps amount to
+        print(f"numfail96 {name}: iteration gaps device - oracle over {len(gaps)} states: {dict((g, gaps.count(g)) for g in sorted(set(gaps)))}")
         for i, x in enumerate(numfail96["states"]):
             e = x[name]
             assert dns[i] == pytest.approx(e["numpy_mips"]["dns"], abs=1e-5)

@@ -10,15 +10,8 @@ from powersystemsreliabilityassessment_amd import api
 from oracle import coracle
 n_cases = int(sys.argv[1]) if len(sys.argv) > 1 else 40
 ORDER = sys.argv[2] if len(sys.argv) > 2 else None           # "tune": every case under an elimination order tuned on the spot (relmc_tune_order)
-rng0 = np.random.default_rng(20261002)
 tot = dict(states=0, status=0, dns=0, it1=0, it2=0, retried=0, dense=0, dense_conv=0, nc_device=0, nc_oracle=0)
-for k in range(n_cases):
-    nb = int(rng0.choice([2, 3, 4, 5, 7, 9, 12, 16, 20, 24, 28, 32, 36, 48, 60, 73, 90, 110]))
-    chords = int(rng0.integers(0, max(1, nb // 2 + 1)))
-    ng = int(rng0.integers(max(2, nb // 3), nb + 8))
-    lbs = int(rng0.integers(1, nb + 1)) if nb > 2 else 1
-    tight = float(rng0.uniform(0.3, 0.9)); par = int(rng0.integers(0, 4)); pminf = float(rng0.choice([0.0, 0.0, 0.25]))
-    seed = 5000 + k
+for k, (seed, nb, chords, ng, lbs, tight, par, pminf) in enumerate(m.fuzz_stream(n_cases)):
     try:
         case = m.random_case(np.random.default_rng(seed), nb, chords, ng, lbs, tight, par, pminf)
         eng = api.Engine(case, elim_order=ORDER)
