@@ -1,6 +1,6 @@
 import os, sys, ctypes as C
-sys.path.insert(0,'/root/repo')
-os.environ['RELMC_LIB_PATH']='/root/repo/powersystemsreliabilityassessment_amd/csrc/ablate/librelmc_pt.so'
+sys.path.insert(0,''+os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+'')
+os.environ['RELMC_LIB_PATH']=''+os.path.dirname(os.path.dirname(os.path.abspath(__file__)))+'/powersystemsreliabilityassessment_amd/csrc/ablate/librelmc_pt.so'
 import numpy as np
 from powersystemsreliabilityassessment_amd import api
 e=api.Engine(); e.nsq_accumulate(1,0,65536)
