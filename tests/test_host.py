@@ -226,6 +226,28 @@ def test_native_comm_init_with_a_deadline_reports_errors_and_stalls():
     assert why == "" and (c.rank, c.world) == (1, 2)
 
 
+def test_a_communicator_whose_peer_stalled_is_never_finalised():
+    """ADVICE r4 (bench.py --comm auto): when a PEER's RCCL bootstrap stalls, this rank's own communicator did come up; dropping the last
+    reference to its Engine would run relmc_ctx_destroy -> ncclCommDestroy against a peer stuck inside RCCL, unguarded.  The fallback pins the
+    (communicator, engine) pair for the life of the process (dist.keep_forever) and the process leaves through os._exit."""
+    import gc
+    import weakref
+
+    class Obj:
+        pass
+    comm, eng = Obj(), Obj()
+    wc, we = weakref.ref(comm), weakref.ref(eng)
+    n0 = rdist.kept_forever()
+    rdist.keep_forever(comm, eng)
+    del comm, eng
+    gc.collect()
+    assert wc() is not None and we() is not None and rdist.kept_forever() == n0 + 1
+    src = open(os.path.join(ROOT, "bench.py")).read()
+    i = src.index("rdist.keep_forever(comm, eng)")
+    assert i < src.index("eng = api.Engine(case, device=local_rank)", i) < src.index("comm = rdist.HostComm(eng, rank, world, device)", i)     # pinned BEFORE the names are rebound
+    assert "rdist.abandoned_threads() or rdist.kept_forever()" in src and "os._exit(0)" in src
+
+
 def test_watchdog_turns_a_stuck_peer_into_a_diagnosis(tmp_path):
     """First contact with N > 1 ranks must not be able to hang: a peer that never enters the collective (here: a gloo rank that sleeps) makes
     the waiting rank print who it is and what it was waiting for and leave with exit code 86 after the guard's limit, instead of sitting in
