@@ -138,10 +138,10 @@ int launch_eval(relmc_ctx* ctx, int mode, EvalArgs& a, int* rows_out, hipEvent_t
 int launch_finalize(relmc_ctx* ctx, int rows)
 {
     if (ctx->tile == 0)
-        hipLaunchKernelGGL(relmc_finalize_kernel<Tile24>, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase),
+        hipLaunchKernelGGL(relmc_finalize_kernel<Tile24>, dim3(FIN_ITEMS), dim3(FIN_THREADS), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile24>*>(ctx->dcase),
                            reinterpret_cast<const PartialT<Tile24>*>(ctx->dpartial), rows, ctx->dacc);
     else
-        hipLaunchKernelGGL(relmc_finalize_kernel<Tile96>, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase),
+        hipLaunchKernelGGL(relmc_finalize_kernel<Tile96>, dim3(FIN_ITEMS), dim3(FIN_THREADS), 0, ctx->stream, reinterpret_cast<const DevCaseT<Tile96>*>(ctx->dcase),
                            reinterpret_cast<const PartialT<Tile96>*>(ctx->dpartial), rows, ctx->dacc);
     HIP_TRY(ctx, hipGetLastError());
     return RELMC_OK;
