@@ -1,4 +1,4 @@
-import sys, time; sys.path.insert(0,'/root/repo')
+import sys, time; import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powersystemsreliabilityassessment_amd import api, case96, dist
 for name, case, n in (("rts24", None, 1_000_000_000), ("rts96", case96.rts96(), 100_000_000)):
     e = api.Engine(case) if case is not None else api.Engine()
