@@ -206,7 +206,8 @@ def main():
         fd1 = os.dup(1)
         os.dup2(2, 1)
         try:
-            with guard(f"torch.distributed.init_process_group({pg_backend})"):
+            # the rendezvous gets three times the collectives' limit: on a fresh box the ranks' first `import torch` takes minutes and need not end together
+            with rdist.Watchdog(3.0 * args.comm_timeout, f"torch.distributed.init_process_group({pg_backend})", rank=rank, world=world, device=local_rank):
                 if pg_backend == "nccl":
                     dist.init_process_group("nccl", rank=rank, world_size=world, device_id=device)
                 else:
