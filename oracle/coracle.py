@@ -14,7 +14,7 @@ import numpy as np
 from powersystemsreliabilityassessment_amd import _abi
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-_SO = os.path.join(_HERE, "librelmc_oracle.so")
+_SO = os.environ.get("RELMC_ORACLE_LIB_PATH") or os.path.join(_HERE, "librelmc_oracle.so")     # override: the sanitizer build (make -C oracle asan)
 
 
 def build(force: bool = False) -> str:
