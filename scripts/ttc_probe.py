@@ -1,5 +1,5 @@
 import sys, time
-sys.path.insert(0, "/root/repo")
+import os; sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from powersystemsreliabilityassessment_amd import api
 e = api.Engine()
 e.nsq_accumulate(1, 0, 1000000)
