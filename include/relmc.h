@@ -99,6 +99,12 @@ typedef struct {
     double z0;                /* 1 */
     double alpha_min;         /* 1e-8 */
     double max_stepsize;      /* 1e10 */
+    int32_t screen;           /* 0 (default): every unit goes through the interior point.  1: zero-curtailment pre-screen: a unit
+                                 for which an explicit dispatch serves all load -- units in service loaded proportionally between Pmin and Pmax, DC
+                                 flows through the base-topology PTDF (one line out: + its LODF column) inside every rating -- has LP optimum 0, so the
+                                 reference's outputs for it are exactly (0, zeros) (mc_simulation.m:57-59, 65) and it is counted without being solved.
+                                 Every output but the iteration statistics is the one of screen = 0; relmc_acc.n_screened counts the skipped units. */
+    int32_t reserved;         /* 0 */
 } relmc_solver_opts;
 
 /* Additive accumulators of one scenario range (what is all-reduced across GPUs). */
@@ -110,6 +116,7 @@ typedef struct {
     int64_t n_nonconverged;   /* RELMC_ST_MAXIT or RELMC_ST_NUMFAIL                    */
     int64_t sum_iters;        /* IPM iterations                                        */
     int64_t comp_fail[RELMC_MAX_COMP]; /* sum over failed scenarios of state_k (nsqMain.m:373-376) */
+    int64_t n_screened;       /* of n: certified zero-curtailment by the pre-screen and not solved (relmc_solver_opts.screen) */
     double sum_dns;           /* sum dns      (nsqMain.m:286)                          */
     double sum_dns2;          /* sum dns^2    (for beta, nsqMain.m:299-301)            */
     double sum_nodal[RELMC_MAX_BUS];   /* sum nodal_dns (nsqMain.m:348)               */

@@ -28,12 +28,14 @@ mutable struct SolverOpts
     singular_policy::Int32; max_it::Int32
     feastol::Cdouble; gradtol::Cdouble; comptol::Cdouble; costtol::Cdouble
     xi::Cdouble; sigma::Cdouble; z0::Cdouble; alpha_min::Cdouble; max_stepsize::Cdouble
+    screen::Int32; reserved::Int32            # screen = 1: zero-curtailment pre-screen (relmc.h), relmc_acc.n_screened counts the skipped units
     SolverOpts() = new()
 end
 
 mutable struct Acc
     n::Int64; n_fail::Int64; n_singular::Int64; n_infeasible::Int64; n_nonconverged::Int64; sum_iters::Int64
     comp_fail::NTuple{MAX_COMP,Int64}
+    n_screened::Int64
     sum_dns::Cdouble; sum_dns2::Cdouble
     sum_nodal::NTuple{MAX_BUS,Cdouble}
     Acc() = new()
@@ -52,9 +54,10 @@ struct SolverOptsC
     singular_policy::Int32; max_it::Int32
     feastol::Cdouble; gradtol::Cdouble; comptol::Cdouble; costtol::Cdouble
     xi::Cdouble; sigma::Cdouble; z0::Cdouble; alpha_min::Cdouble; max_stepsize::Cdouble
+    screen::Int32; reserved::Int32
 end
 SolverOptsC(o::SolverOpts) = SolverOptsC(o.singular_policy, o.max_it, o.feastol, o.gradtol, o.comptol, o.costtol, o.xi, o.sigma, o.z0,
-                                         o.alpha_min, o.max_stepsize)
+                                         o.alpha_min, o.max_stepsize, o.screen, o.reserved)
 
 "relmc_nsq_opts (include/relmc.h): the options of the whole nsqMain loop"
 struct NsqOpts
@@ -66,8 +69,8 @@ struct NsqOpts
 end
 
 # relmc_nsq_result is read out of a byte buffer at these offsets (Acc and Indices are mutable mirrors and cannot be embedded)
-const NSQ_RESULT_BYTES = 8 * (6 + MAX_COMP + 2 + MAX_BUS) + 8 * (7 + MAX_BUS + MAX_COMP) + 40
-const NSQ_RESULT_IDX = 8 * (6 + MAX_COMP + 2 + MAX_BUS)
+const NSQ_RESULT_BYTES = 8 * (7 + MAX_COMP + 2 + MAX_BUS) + 8 * (7 + MAX_BUS + MAX_COMP) + 40
+const NSQ_RESULT_IDX = 8 * (7 + MAX_COMP + 2 + MAX_BUS)
 const NSQ_RESULT_TAIL = NSQ_RESULT_IDX + 8 * (7 + MAX_BUS + MAX_COMP)     # checkpoints, converged, wall_seconds, kernel_seconds, batches
 
 "TestSystem after the load model of nsqMain.m:121-153 (0-based indices inside)."
@@ -392,7 +395,7 @@ end
 
 # relmc_seq_result is read out of a byte buffer at these offsets (like relmc_nsq_result)
 const SEQ_RESULT_ACC = 56                                                   # final_year, converged, eens, cov, lole, lolf, plc, n_contingency
-const SEQ_RESULT_NODAL = SEQ_RESULT_ACC + 8 * (6 + MAX_COMP + 2 + MAX_BUS)
+const SEQ_RESULT_NODAL = SEQ_RESULT_ACC + 8 * (7 + MAX_COMP + 2 + MAX_BUS)
 const SEQ_RESULT_IMP = SEQ_RESULT_NODAL + 8 * MAX_BUS
 const SEQ_RESULT_TAIL = SEQ_RESULT_IMP + 8 * MAX_COMP                       # wall_seconds, kernel_seconds
 const SEQ_RESULT_BYTES = SEQ_RESULT_TAIL + 16
@@ -443,14 +446,14 @@ end
 # without a Julia installation.  (name, sizeof, [(field, offset) ...])
 const LAYOUT = [
     ("relmc_case_desc", 128, [("base_mva", 0), ("nb", 8), ("ref_bus", 24), ("bus_pd", 32), ("always_up", 112), ("total_load", 120)]),
-    ("relmc_solver_opts", 80, [("singular_policy", 0), ("max_it", 4), ("feastol", 8), ("max_stepsize", 72)]),
-    ("relmc_acc", 8 * (6 + MAX_COMP + 2 + MAX_BUS), [("n", 0), ("comp_fail", 48), ("sum_dns", 48 + 8 * MAX_COMP), ("sum_nodal", 64 + 8 * MAX_COMP)]),
+    ("relmc_solver_opts", 88, [("singular_policy", 0), ("max_it", 4), ("feastol", 8), ("max_stepsize", 72), ("screen", 80)]),
+    ("relmc_acc", 8 * (7 + MAX_COMP + 2 + MAX_BUS), [("n", 0), ("comp_fail", 48), ("n_screened", 48 + 8 * MAX_COMP), ("sum_dns", 56 + 8 * MAX_COMP), ("sum_nodal", 72 + 8 * MAX_COMP)]),
     ("relmc_indices", 8 * (7 + MAX_BUS + MAX_COMP), [("n", 0), ("edns", 8), ("nodal_eens", 56), ("comp_importance", 56 + 8 * MAX_BUS)]),
     ("relmc_db_stats", 32, [("rows", 0), ("samples", 8), ("new_rows", 16), ("batch_distinct", 24)]),
     ("relmc_seq_year", 32, [("ens", 0), ("dlc", 8), ("nlc", 16), ("n_contingency", 24)]),
     ("relmc_hl1_acc", 40, [("n", 0), ("sum_lole", 8), ("sum_eue2", 32)]),
-    ("relmc_nsq_opts", 168, [("beta_limit", 0), ("max_samples", 8), ("batch", 16), ("seed", 24), ("hours_per_year", 32), ("solver", 40), ("history_cap", 120), ("beta_history", 128), ("plc_history", 152), ("distinct_states", 160)]),
-    ("relmc_seq_opts", 144, [("cov_threshold", 0), ("max_years", 8), ("batch_years", 12), ("seed", 16), ("curtail_threshold", 24), ("solver", 32), ("years_cap", 112), ("results_year", 120), ("cum_cov", 136)]),
+    ("relmc_nsq_opts", 176, [("beta_limit", 0), ("max_samples", 8), ("batch", 16), ("seed", 24), ("hours_per_year", 32), ("solver", 40), ("history_cap", 128), ("beta_history", 136), ("plc_history", 160), ("distinct_states", 168)]),
+    ("relmc_seq_opts", 152, [("cov_threshold", 0), ("max_years", 8), ("batch_years", 12), ("seed", 16), ("curtail_threshold", 24), ("solver", 32), ("years_cap", 120), ("results_year", 128), ("cum_cov", 144)]),
     ("relmc_seq_result", SEQ_RESULT_BYTES, [("final_year", 0), ("converged", 4), ("eens", 8), ("plc", 40), ("n_contingency", 48), ("acc", SEQ_RESULT_ACC), ("nodal_eens_avg", SEQ_RESULT_NODAL), ("comp_importance", SEQ_RESULT_IMP), ("wall_seconds", SEQ_RESULT_TAIL), ("kernel_seconds", SEQ_RESULT_TAIL + 8)]),
     ("relmc_nsq_result", NSQ_RESULT_BYTES, [("acc", 0), ("idx", NSQ_RESULT_IDX), ("checkpoints", NSQ_RESULT_TAIL), ("converged", NSQ_RESULT_TAIL + 8), ("wall_seconds", NSQ_RESULT_TAIL + 16), ("kernel_seconds", NSQ_RESULT_TAIL + 24), ("batches", NSQ_RESULT_TAIL + 32)]),
 ]

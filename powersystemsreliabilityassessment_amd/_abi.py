@@ -46,6 +46,7 @@ class SolverOpts(C.Structure):
         ("feastol", C.c_double), ("gradtol", C.c_double), ("comptol", C.c_double),
         ("costtol", C.c_double), ("xi", C.c_double), ("sigma", C.c_double), ("z0", C.c_double),
         ("alpha_min", C.c_double), ("max_stepsize", C.c_double),
+        ("screen", C.c_int32), ("reserved", C.c_int32),
     ]
 
 
@@ -54,11 +55,12 @@ class Acc(C.Structure):
         ("n", C.c_int64), ("n_fail", C.c_int64), ("n_singular", C.c_int64),
         ("n_infeasible", C.c_int64), ("n_nonconverged", C.c_int64), ("sum_iters", C.c_int64),
         ("comp_fail", C.c_int64 * RELMC_MAX_COMP),
+        ("n_screened", C.c_int64),
         ("sum_dns", C.c_double), ("sum_dns2", C.c_double),
         ("sum_nodal", C.c_double * RELMC_MAX_BUS),
     ]
 
-    N_INT = 6 + RELMC_MAX_COMP
+    N_INT = 6 + RELMC_MAX_COMP + 1
     N_DBL = 2 + RELMC_MAX_BUS
 
     def to_arrays(self):
@@ -144,7 +146,7 @@ def default_solver_opts(policy: int = RELMC_REFERENCE_EMULATE) -> SolverOpts:
     """MIPS defaults MATPOWER uses for OPF_ALG_DC=200 (nsqMain.m:185-186)."""
     return SolverOpts(singular_policy=policy, max_it=150, feastol=5e-6, gradtol=1e-6,
                       comptol=1e-6, costtol=1e-6, xi=0.99995, sigma=0.1, z0=1.0,
-                      alpha_min=1e-8, max_stepsize=1e10)
+                      alpha_min=1e-8, max_stepsize=1e10, screen=0, reserved=0)
 
 
 class CaseHolder:

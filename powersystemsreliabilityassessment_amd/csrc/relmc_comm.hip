@@ -275,7 +275,8 @@ int32_t relmc_comm_allreduce_acc(relmc_ctx* ctx, relmc_acc* acc)
     if (!ctx->comm) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_allreduce_acc: relmc_comm_init has not been called");
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->dacc, acc, sizeof(*acc), hipMemcpyHostToDevice, ctx->stream));
-    constexpr size_t NI = 6 + RELMC_MAX_COMP, ND = 2 + RELMC_MAX_BUS;
+    constexpr size_t NI = 6 + RELMC_MAX_COMP + 1, ND = 2 + RELMC_MAX_BUS;
+    static_assert(sizeof(relmc_acc) == 8 * (NI + ND), "relmc_acc = NI int64 then ND doubles");
     long long* di = reinterpret_cast<long long*>(ctx->dacc);
     double* dd = reinterpret_cast<double*>(di + NI);
     Guard g(ctx, "ncclAllReduce (relmc_acc)", ctx->comm_nranks, ctx->comm_rank);

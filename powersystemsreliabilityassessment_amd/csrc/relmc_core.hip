@@ -344,6 +344,7 @@ void relmc_solver_opts_default(relmc_solver_opts* o)
     o->max_it = 150;
     o->feastol = 5e-6; o->gradtol = 1e-6; o->comptol = 1e-6; o->costtol = 1e-6;
     o->xi = 0.99995; o->sigma = 0.1; o->z0 = 1.0; o->alpha_min = 1e-8; o->max_stepsize = 1e10;
+    o->screen = 0; o->reserved = 0;
 }
 
 void relmc_nsq_opts_default(relmc_nsq_opts* o)
@@ -477,6 +478,7 @@ void relmc_acc_merge(relmc_acc* d, const relmc_acc* s)
     d->n += s->n; d->n_fail += s->n_fail; d->n_singular += s->n_singular; d->n_infeasible += s->n_infeasible;
     d->n_nonconverged += s->n_nonconverged; d->sum_iters += s->sum_iters;
     for (int k = 0; k < RELMC_MAX_COMP; ++k) d->comp_fail[k] += s->comp_fail[k];
+    d->n_screened += s->n_screened;
     d->sum_dns += s->sum_dns; d->sum_dns2 += s->sum_dns2;
     for (int i = 0; i < RELMC_MAX_BUS; ++i) d->sum_nodal[i] += s->sum_nodal[i];
 }

@@ -146,7 +146,7 @@ int db_ensure(relmc_ctx* ctx, int64_t need)
 bool same_opts(const relmc_solver_opts& a, const relmc_solver_opts& b)
 {
     return a.singular_policy == b.singular_policy && a.max_it == b.max_it && a.feastol == b.feastol && a.gradtol == b.gradtol && a.comptol == b.comptol &&
-           a.costtol == b.costtol && a.xi == b.xi && a.sigma == b.sigma && a.z0 == b.z0 && a.alpha_min == b.alpha_min && a.max_stepsize == b.max_stepsize;
+           a.costtol == b.costtol && a.xi == b.xi && a.sigma == b.sigma && a.z0 == b.z0 && a.alpha_min == b.alpha_min && a.max_stepsize == b.max_stepsize && a.screen == b.screen;
 }
 
 // nsqMain.m:282-301, 348-349, 366-376: count-weighted sums over every row of the database -> *acc_out
@@ -169,7 +169,7 @@ int db_accumulate(relmc_ctx* ctx, relmc_acc* acc_out)
     }
     hipLaunchKernelGGL(relmc_db_reduce_kernel, dim3((unsigned)nblk), dim3(256), 0, ctx->stream, ow, ctx->nb, ctx->ncomp, 1e-4, ctx->db_keys, ctx->db_count,
                        ctx->db_dns, ctx->db_meta, ctx->db_nodal, rows, per, ctx->db_partial);
-    hipLaunchKernelGGL(relmc_db_final_kernel, dim3(FIN_ITEMS), dim3(64), 0, ctx->stream, ctx->db_partial, (int)nblk, ctx->dacc);
+    hipLaunchKernelGGL(relmc_db_final_kernel, dim3(sizeof(DevAcc) / 8), dim3(64), 0, ctx->stream, ctx->db_partial, (int)nblk, ctx->dacc);
     HIP_TRY(ctx, hipGetLastError());
     HIP_TRY(ctx, hipMemcpyAsync(acc_out, ctx->dacc, sizeof(*acc_out), hipMemcpyDeviceToHost, ctx->stream));
     HIP_TRY(ctx, hipStreamSynchronize(ctx->stream));

@@ -271,14 +271,14 @@ __global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, in
                                                               const int32_t* __restrict__ meta, const double* __restrict__ nodal,
                                                               uint64_t rows, uint64_t chunk, DevAcc* __restrict__ partial)
 {
-    __shared__ unsigned long long si[6 + 256];
+    __shared__ unsigned long long si[6 + 256 + 1];
     __shared__ double sd[2][256];
     __shared__ double sn[8][128];
     const int t = threadIdx.x;
-    for (int k = t; k < 6 + 256; k += 256) si[k] = 0ull;
+    for (int k = t; k < 6 + 256 + 1; k += 256) si[k] = 0ull;
     __syncthreads();
     const uint64_t lo = (uint64_t)blockIdx.x * chunk, hi = lo + chunk < rows ? lo + chunk : rows;
-    unsigned long long c_n = 0, c_fail = 0, c_sing = 0, c_inf = 0, c_nc = 0, c_it = 0;
+    unsigned long long c_n = 0, c_fail = 0, c_sing = 0, c_inf = 0, c_nc = 0, c_it = 0, c_scr = 0;
     double s1 = 0.0, s2 = 0.0;
     for (uint64_t r = lo + t; r < hi; r += 256) {
         const unsigned long long c = count[r];
@@ -290,6 +290,7 @@ __global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, in
         if (st == 3u) c_sing += c;
         if (st == 1u || st == 2u) c_nc += c;
         if (m & 4u) c_inf += c;
+        if (m & 8u) c_scr += c;                         // row certified by the pre-screen, never solved (relmc_screen.hip)
         if (d != 0.0) { const double cd = (double)c; s1 = __builtin_fma(cd, d, s1); s2 = __builtin_fma(cd * d, d, s2); }
         if (d > fail_threshold) {                        // nsqMain.m:270
             c_fail += c;
@@ -299,7 +300,7 @@ __global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, in
             }
         }
     }
-    atomicAdd(&si[0], c_n); atomicAdd(&si[1], c_fail); atomicAdd(&si[2], c_sing); atomicAdd(&si[3], c_inf); atomicAdd(&si[4], c_nc); atomicAdd(&si[5], c_it);
+    atomicAdd(&si[0], c_n); atomicAdd(&si[1], c_fail); atomicAdd(&si[2], c_sing); atomicAdd(&si[3], c_inf); atomicAdd(&si[4], c_nc); atomicAdd(&si[5], c_it); atomicAdd(&si[6 + 256], c_scr);
     sd[0][t] = s1; sd[1][t] = s2;
     // nodal columns: thread (g, bl) sums bus columns bl, bl + 32, ... over the rows lo + g, lo + g + 8, ...
     const int g = t >> 5, bl = t & 31;
@@ -322,7 +323,7 @@ __global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, in
     }
     DevAcc& out = partial[blockIdx.x];
     long long* oi = reinterpret_cast<long long*>(&out);
-    for (int k = t; k < 6 + 256; k += 256) oi[k] = (long long)si[k];
+    for (int k = t; k < 6 + 256 + 1; k += 256) oi[k] = (long long)si[k];
     if (t == 0) { out.sum_dns = sd[0][0]; out.sum_dns2 = sd[1][0]; }
     if (t < 128) out.sum_nodal[t] = ((sn[0][t] + sn[1][t]) + (sn[2][t] + sn[3][t])) + ((sn[4][t] + sn[5][t]) + (sn[6][t] + sn[7][t]));
     (void)ncomp;
@@ -331,7 +332,7 @@ __global__ void __launch_bounds__(256) relmc_db_reduce_kernel(int ow, int nb, in
 // stage 2: one wavefront per accumulator word sums the block partials lane-strided and combines them by a fixed butterfly
 __global__ void __launch_bounds__(64) relmc_db_final_kernel(const DevAcc* __restrict__ partial, int nblocks, DevAcc* __restrict__ out)
 {
-    constexpr int NI = 6 + 256;
+    constexpr int NI = 6 + 256 + 1;
     const int item = blockIdx.x, lane = threadIdx.x;
     long long si = 0; double sd = 0.0;
     for (int b = lane; b < nblocks; b += 64) {

@@ -161,10 +161,11 @@ struct EvalArgs {
     uint64_t dense_stride;
 };
 
-// device image of relmc_acc (include/relmc.h): 6 + 256 int64, then 2 + 128 doubles
+// device image of relmc_acc (include/relmc.h): 6 + 256 + 1 int64, then 2 + 128 doubles
 struct DevAcc {
     long long n, n_fail, n_singular, n_infeasible, n_nonconverged, sum_iters;
     long long comp_fail[256];
+    long long n_screened;           // never written by the evaluation kernels: the pre-screen's count is added on the host (relmc_screen.hip)
     double sum_dns, sum_dns2;
     double sum_nodal[128];
 };

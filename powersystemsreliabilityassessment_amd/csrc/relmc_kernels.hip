@@ -1363,7 +1363,7 @@ __global__ void __launch_bounds__(FIN_THREADS) relmc_finalize_kernel(const DevCa
     __syncthreads();
     if (tid == 0) {
         si = (wi[0] + wi[1]) + (wi[2] + wi[3]); sd = (wd[0] + wd[1]) + (wd[2] + wd[3]);
-        if (item < 6) (&out->n)[item] = si;
+        if (item < 6) { (&out->n)[item] = si; if (item == 0) out->n_screened = 0; }     // the pre-screen's count is the host's to add (the image may hold an all-reduce's or the database's)
         else if (item == 6) out->sum_dns = sd;
         else if (item == 7) out->sum_dns2 = sd;
         else if (item < 8 + 256) out->comp_fail[item - 8] = si;

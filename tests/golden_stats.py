@@ -10,6 +10,12 @@ be reproduced sample by sample (MATLAB's global stream), so the pin is statistic
   SEQ   two-sample Kolmogorov-Smirnov of the 1 245 golden annual (ens, dlc, nlc) against the device's years (seqMain.m:162-176); nodal
         EENS per bus and component importance against the spread of device replicas of the golden run's length (seqMain.m:218, 233).
 
+  NSQ   per-checkpoint batch fingerprint (round 6): edns_history and beta_history are exact enough to reconstruct, for each of the golden run's
+        1 000 batches of 100 samples, the batch sum S_k of dns and the batch sum of squares Q_k (nsqMain.m:286-287, 299-308).  Every S_k is an
+        integer number of MW plus a 0.2-5 micro-MW fractional part: the sum of MIPS' termination residuals f + 2850 (mc_simulation.m:54) over
+        the batch's shed samples -- a reference-held pin on WHERE the interior point stops (comptol / sigma / xi / z0 all move it).  34 of
+        the Q_k carry one sample of 1 425 MW = half the system load: the isolated-bus state of REFERENCE_EMULATE, in the reference's own data.
+
 Every function returns plain numbers; the callers (tests/test_gpu_parity.py, tests/test_seq.py, tests/tools/golden_pin.py) decide what to assert.
 """
 from __future__ import annotations
@@ -116,3 +122,47 @@ def replica_chi2_rank(golden: np.ndarray, replicas: np.ndarray, keep: np.ndarray
     Tg = float((((g - m) ** 2) / v).sum())
     p = (1.0 + float((Tr >= Tg).sum())) / (R + 1.0)
     return Tg, p, Tr
+
+
+# ---- per-checkpoint batch fingerprint of an NSQ run (nsqMain.m:286-287, 299-308: edns_history, beta_history) -------------------------------
+def batch_sums(edns_history, samples_per_batch: int) -> np.ndarray:
+    """S_k = sum of dns over the k-th batch, from edns_history[k] = (S_1 + ... + S_k) / (k * samples_per_batch) (nsqMain.m:286-287, 306).
+    Exact to ~2 ulp of the running total (3e-10 MW at 1e5 samples), i.e. three orders below the termination residuals it resolves."""
+    e = np.asarray(edns_history, dtype=np.float64)
+    N = np.arange(1, e.size + 1, dtype=np.float64) * float(samples_per_batch)
+    return np.diff(e * N, prepend=0.0)
+
+
+def batch_sumsq(beta_history, edns_history, samples_per_batch: int) -> np.ndarray:
+    """Q_k = sum of dns^2 over the k-th batch: nsqMain.m:299-301 has beta = sqrt(sum c (d - e)^2) / N / e, so the running
+    sum of squares is (beta N e)^2 + N e^2.  Good to ~1e-7 relative of the running total: integer-MW^2 resolution, not the micro-MW one."""
+    e = np.asarray(edns_history, dtype=np.float64); b = np.asarray(beta_history, dtype=np.float64)
+    N = np.arange(1, e.size + 1, dtype=np.float64) * float(samples_per_batch)
+    return np.diff((b * N * e) ** 2 + N * e * e, prepend=0.0)
+
+
+def batch_fingerprint(beta_history, edns_history, samples_per_batch: int) -> dict:
+    """dict(S, Q, whole, frac): whole = round(S) (MW shed by the batch when every shed state's LP value is an integer, as on RTS-24 with its
+    integer unit sizes and loads), frac = S - whole = the batch's sum of termination residuals."""
+    S = batch_sums(edns_history, samples_per_batch)
+    Q = batch_sumsq(beta_history, edns_history, samples_per_batch)
+    whole = np.round(S)
+    return dict(S=S, Q=Q, whole=whole, frac=S - whole)
+
+
+def event_batches(Q: np.ndarray, dns_event: float, margin: float = 0.985):
+    """Batches holding at least one sample of dns >= margin * dns_event (Q_k >= (margin * dns_event)^2): boolean mask."""
+    return np.asarray(Q) >= (margin * dns_event) ** 2
+
+
+def event_magnitude(Q: np.ndarray, mask: np.ndarray):
+    """Estimate of the event's dns from the batch sums of squares alone: sqrt(mean Q over event batches - mean Q over the others), with its
+    standard error (the others' spread carries over to the event batches' remainder).  Returns (D_hat, se)."""
+    Q = np.asarray(Q, dtype=np.float64); m = np.asarray(mask, dtype=bool)
+    k = int(m.sum())
+    if k == 0:
+        return float("nan"), float("nan")
+    d2 = Q[m].mean() - Q[~m].mean()
+    se2 = Q[~m].std(ddof=1) * np.sqrt(1.0 / k + 1.0 / (~m).sum())
+    D = float(np.sqrt(max(d2, 0.0)))
+    return D, float(se2 / (2.0 * D)) if D > 0 else float("inf")

@@ -568,6 +568,86 @@ def test_nsq_golden_joint_pin(engine, golden, capsys):
     np.testing.assert_allclose(e["nodal"]["mean"][case.bus_pd == 0], 0.0, atol=0)
 
 
+def _device_fingerprint(engine, seeds, n, distinct, policy=api.REFERENCE_EMULATE):
+    """Batch fingerprints (tests/golden_stats.py) of `len(seeds)` device runs of n samples at the reference's checkpoint spacing of 100,
+    concatenated (separate seeds keep every running total below 4e6 MW, i.e. the reconstruction exact to 1e-9 MW)."""
+    import golden_stats as gs
+    parts, n_fail = [], 0
+    for seed in seeds:
+        r = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=100, seed=seed, distinct_states=distinct, mpopt=api.mpoption(policy))
+        assert r.current_iteration == n and len(r.edns_history) == n // 100 and r.n_nonconverged == 0
+        fp = gs.batch_fingerprint(r.beta_history, r.edns_history, 100)
+        fp["nfail"] = np.round(np.diff(r.plc_history * 100.0 * np.arange(1, n // 100 + 1), prepend=0.0))      # shed samples per batch (nsqMain.m:295-296)
+        assert fp["nfail"].sum() == r.acc.n_fail
+        parts.append(fp)
+    out = {k: np.concatenate([p[k] for p in parts]) for k in parts[0]}
+    # a batch holding a state whose LP value is not a whole number of MW (a binding line limit; none among the golden run's 1e5 samples,
+    # ~1 batch in 2 000 here) has no readable residual sum: those batches are set aside, counted and bounded
+    out["clean"] = (out["frac"] > 0) & (out["frac"] < 1e-4)
+    return out
+
+
+@pytest.mark.parametrize("path", ["every_sample", "database"])
+def test_termination_fingerprint_device_vs_golden(engine, oracle, golden, path, capsys):
+    """WHERE the interior point stops, pinned to reference-held data (VERDICT r5 'do this' 1b): the golden histories give, per batch of 100
+    samples, the sum of MIPS' termination residuals f + 2850 over the batch's shed samples (0.26-4.9 micro-MW on a whole-MW batch sum;
+    nsqMain.m:286-287, 304-308, mc_simulation.m:54).  The device's histories at the same spacing, 2e6 samples, every sample solved (MODE 0)
+    and through the state database: two-sample KS of the residual sums against the golden run's, mean residual per shed sample within 3 %,
+    the isolated-bus batches (sum of squares >= 1404^2 MW^2) at the golden rate; and batch by batch against the C oracle on seed 1.
+    tests/test_oracle.py shows the same statistic rejecting comptol x/÷ 10, sigma 0.2, xi 0.9995, z0 2 at p < 1e-70."""
+    import golden_stats as gs
+    from scipy import stats
+    distinct = "database" if path == "database" else False
+    g = gs.batch_fingerprint(golden["beta_history"], golden["edns_history"], golden["samples_per_batch"])
+    g_fail = golden["accumulated_lole"] / 8760.0 * golden["n_samples"]
+    d = _device_fingerprint(engine, range(1, 11), 200_000, distinct)
+    assert d["frac"].size == 20_000
+    cl = d["clean"]
+    assert cl.mean() > 0.995
+    D, p = gs.ks_two_sample(g["frac"], d["frac"][cl])
+    per_g, per_d = g["frac"].sum() / g_fail, d["frac"][cl].sum() / d["nfail"][cl].sum()
+    rate = float(gs.event_batches(d["Q"], 1425.0).mean())
+    p_ev = stats.binomtest(34, 1000, rate).pvalue
+    Dw, pw = gs.ks_two_sample(g["whole"], d["whole"]); Dq, pq = gs.ks_two_sample(g["Q"], d["Q"])
+    # batch by batch against the oracle's own database loop on seed 1 (same samples, same checkpoints)
+    o = oracle.nsq_database(1, beta_limit=0.0, max_iterations=200_000, samples_per_batch=100)
+    of = gs.batch_fingerprint(o["beta_history"], o["edns_history"], 100)
+    df = {k: v[:2000] for k, v in d.items()}
+    assert np.array_equal(df["whole"], of["whole"])
+    diff = np.abs(df["frac"] - of["frac"])
+    with capsys.disabled():
+        print(f"\n   termination residuals, device ({path}, 2e6 samples) vs golden: KS D = {D:.4f} p = {p:.3f}; per shed sample {per_d:.4e} vs {per_g:.4e} MW; "
+              f"isolated-bus batches {rate:.4f} vs 0.0340 (binomial p = {p_ev:.3f}); whole-MW KS p = {pw:.3f}, sum-of-squares KS p = {pq:.3f}; "
+              f"vs C oracle per batch: median |diff| {np.median(diff):.1e}, max {diff.max():.1e} MW; batches with a non-integer LP value: {int((~cl).sum())} of {cl.size}", end="")
+    assert p > 0.01 and per_d == pytest.approx(per_g, rel=0.03)
+    assert d["frac"][cl].min() > 1e-7 and d["frac"][cl].max() < 8e-6
+    assert p_ev > 0.01 and pw > 1e-3 and pq > 1e-3
+    assert np.median(diff) < 2e-9 and np.quantile(diff, 0.99) < 2e-8 and diff.max() < 1e-6
+
+
+def test_fingerprint_tells_the_policies_apart_on_the_device(engine, golden, capsys):
+    """1c: whole-MW parts and sums of squares of the batches, device under both policies against the golden run (zero-inflated mixtures like
+    the annual ENS of the sequential track).  The KS statistics do not separate the policies; the count of batches that hold a ~1 425 MW
+    sample does: golden 34 of 1 000, REFERENCE_EMULATE 3.5 %, PHYSICAL 0.05 % -- rejected."""
+    import golden_stats as gs
+    from scipy import stats
+    g = gs.batch_fingerprint(golden["beta_history"], golden["edns_history"], golden["samples_per_batch"])
+    out = {}
+    for name, pol in (("emulate", api.REFERENCE_EMULATE), ("physical", api.PHYSICAL)):
+        d = _device_fingerprint(engine, range(21, 26), 200_000, "database", pol)
+        rate = float(gs.event_batches(d["Q"], 1425.0).mean())
+        out[name] = dict(rate=rate, p_event=stats.binomtest(34, 1000, max(rate, 1e-4)).pvalue, p_whole=gs.ks_two_sample(g["whole"], d["whole"])[1],
+                         p_q=gs.ks_two_sample(g["Q"], d["Q"])[1], p_frac=gs.ks_two_sample(g["frac"], d["frac"][d["clean"]])[1])
+    with capsys.disabled():
+        for name, v in out.items():
+            print(f"\n   golden batches vs device {name}: event-batch rate {v['rate']:.4f} (binomial p = {v['p_event']:.2e}), whole-MW KS p = {v['p_whole']:.3f}, "
+                  f"sum-of-squares KS p = {v['p_q']:.3f}, residual KS p = {v['p_frac']:.3f}", end="")
+    assert out["emulate"]["p_event"] > 0.01 and out["physical"]["p_event"] < 1e-12
+    for v in out.values():
+        assert v["p_whole"] > 1e-3 and v["p_frac"] > 1e-3
+    assert out["emulate"]["p_q"] > 1e-3
+
+
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
 def test_sampled_state_contract_2e5(engine, oracle, policy):
     """The numerical contract of the shipped arithmetic on SAMPLED states, not only on the fixtures: the first 2e5 samples of seed 1, device

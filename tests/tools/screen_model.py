@@ -1,0 +1,123 @@
+"""Host-only model of the zero-curtailment certificate (SURVEY 8f rank 4 'copper-sheet pre-screen', VERDICT r5 'do this' 2-i).  TEST TOOL: numpy + the
+C oracle, no GPU.
+
+A sampled state is CERTIFIED when an explicit dispatch serves all load: units in service dispatched proportionally between Pmin and Pmax,
+DC flows through the base-topology PTDF (one line out: + LODF column) inside every rating.  For such a state the LP optimum is zero curtailment,
+and the reference's outputs are exactly (0, zeros) whatever MIPS' trajectory was (mc_simulation.m:57-59 zeroes dns < 0.1, :65 reports the nodal
+split only when dns > 0).  Reports the certified share and counts false certificates against the oracle's dns.
+
+  python tests/tools/screen_model.py rts24 2000000      |  rts96 300000  |  seq 20
+"""
+from __future__ import annotations
+
+import os
+import sys
+import time
+
+import numpy as np
+
+ROOT = os.path.dirname(os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+sys.path.insert(0, ROOT)
+
+
+def tables(case):
+    """PTDF [nl, nb] (reference bus column = 0), LODF [nl, nl] (column m: flow change per unit pre-outage flow of line m; NaN column = bridge)."""
+    nb, nl = case.nb, case.nl
+    f, t, b = case.br_from, case.br_to, case.br_b
+    Bf = np.zeros((nl, nb)); Bf[np.arange(nl), f] = b; Bf[np.arange(nl), t] = -b
+    A = np.zeros((nl, nb)); A[np.arange(nl), f] = 1.0; A[np.arange(nl), t] = -1.0
+    Bbus = A.T @ Bf
+    keep = np.arange(nb) != case.ref_bus
+    X = np.zeros((nb, nb)); X[np.ix_(keep, keep)] = np.linalg.inv(Bbus[np.ix_(keep, keep)])
+    ptdf = Bf @ X
+    H = ptdf @ A.T                                   # H[l, m] = flow on l per unit injected at from(m), withdrawn at to(m)
+    lodf = np.full((nl, nl), np.nan)
+    for m in range(nl):
+        den = 1.0 - H[m, m]
+        if abs(den) > 1e-8:
+            lodf[:, m] = H[:, m] / den
+            lodf[m, m] = -1.0
+    return ptdf, lodf
+
+
+def certify(case, ptdf, lodf, states, load_scale=1.0, margin=1e-9, max_lines_out=1, variant="prop"):
+    """certified[n] (bool) for states[n, ncomp] (1 = failed)."""
+    st = np.asarray(states, dtype=bool)
+    n = st.shape[0]
+    ng, nl, nb = case.ng, case.nl, case.nb
+    on = ~st[:, :ng]
+    pmin, pmax = case.inj_pmin[:ng], case.inj_pmax[:ng]
+    scale = np.broadcast_to(np.asarray(load_scale, dtype=np.float64), (n,))
+    L = case.total_load * scale
+    lo = on @ pmin; hi = on @ pmax
+    ok = (lo <= L) & (L <= hi) & (hi > lo)
+    t = np.where(ok, (L - lo) / np.where(hi > lo, hi - lo, 1.0), 0.0)
+    pg = on * (pmin[None, :] + t[:, None] * (pmax - pmin)[None, :])
+    Cg = np.zeros((ng, nb)); Cg[np.arange(ng), case.inj_bus[:ng]] = 1.0
+    inj = pg @ Cg - scale[:, None] * case.bus_pd[None, :]
+    F = inj @ ptdf.T                                                   # MW
+    lout = st[:, ng:]
+    nout = lout.sum(1)
+    ok &= nout <= max_lines_out
+    one = np.flatnonzero(ok & (nout == 1))
+    if one.size:
+        m = lout[one].argmax(1)
+        col = lodf[:, m].T                                             # [k, nl]
+        bridge = np.isnan(col[:, 0])
+        Fm = F[one, m]
+        F[one] = np.where(bridge[:, None], np.inf, F[one] + np.nan_to_num(col) * Fm[:, None])
+    lim = np.where(case.br_rate > 0, case.br_rate, np.inf)[None, :]
+    ok &= np.all(np.abs(F) <= lim * (1.0 - margin), axis=1)
+    return ok
+
+
+def seq_model(n_years):
+    """Sequential track (seqMain.m:97-133): contingency hours of n_years simulated years, each with its hourly load factor."""
+    from oracle import coracle
+    from powersystemsreliabilityassessment_amd import case24, loadcurve, seq
+    case = case24.rts24()
+    ptdf, lodf = tables(case)
+    orc = coracle.Oracle(case)
+    rel = seq.seqmeantime(); lf = loadcurve.anloducurve(8736)[2]
+    tot = cont = cert_n = zero_n = false_n = 0
+    cert_by = {0: 0, 1: 0}
+    for y in range(n_years):
+        st = orc.seq_mcsampling(rel, 8736, 1, y, 1)
+        hrs = np.flatnonzero(st.any(1))
+        r = orc.seq_mcsimulation(st[hrs], lf[hrs], nthreads=16)
+        for mlo in (0, 1):
+            c = certify(case, ptdf, lodf, st[hrs], load_scale=lf[hrs], max_lines_out=mlo)
+            cert_by[mlo] += int(c.sum())
+        false_n += int((c & (r["dns"] != 0)).sum())
+        tot += 8736; cont += hrs.size; zero_n += int((r["dns"] == 0).sum())
+    print(f"seq: {n_years} years, contingency hours {cont} of {tot} ({cont / tot:.4f}); zero-dns share of them {zero_n / cont:.5f}")
+    for mlo in (0, 1):
+        print(f"  proportional, <= {mlo} lines out: certified {cert_by[mlo] / cont:.5f} of the contingency hours")
+    print(f"  FALSE certificates {false_n}")
+
+
+def main():
+    from oracle import coracle
+    from powersystemsreliabilityassessment_amd import case24, case96
+    what = sys.argv[1] if len(sys.argv) > 1 else "rts24"
+    n = int(float(sys.argv[2])) if len(sys.argv) > 2 else 200000
+    if what == "seq":
+        return seq_model(n)
+    case = case96.rts96() if what == "rts96" else case24.rts24()
+    ptdf, lodf = tables(case)
+    orc = coracle.Oracle(case)
+    t0 = time.time()
+    d = orc.nsq_database(1, beta_limit=0.0, max_iterations=n, samples_per_batch=min(n, 100000))
+    c = d["count"].astype(np.float64); N = c.sum()
+    print(f"{what}: {int(N)} samples, {len(c)} distinct states, oracle {time.time() - t0:.1f} s; zero-dns share {c[d['dns'] == 0].sum() / N:.4f}")
+    nout = d["states"][:, case.ng:].sum(1)
+    print("  lines out 0/1/2+: %.4f %.4f %.4f" % tuple(c[m].sum() / N for m in (nout == 0, nout == 1, nout >= 2)))
+    for mlo in (0, 1):
+        cert = certify(case, ptdf, lodf, d["states"], max_lines_out=mlo)
+        false = cert & (d["dns"] != 0)
+        print(f"  proportional, <= {mlo} lines out: certified {c[cert].sum() / N:.4f} of samples ({cert.sum()} states), "
+              f"{c[cert].sum() / c[d['dns'] == 0].sum():.4f} of the zero-dns samples; FALSE certificates {int(false.sum())}")
+
+
+if __name__ == "__main__":
+    main()
