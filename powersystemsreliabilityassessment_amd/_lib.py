@@ -177,6 +177,9 @@ def load():
     L.relmc_db_export.restype = C.c_int32
     L.relmc_db_import.argtypes = [vp, C.c_void_p, C.c_int64, u8p, _abi.c_int64_p, dp, dp, i32p, i32p, u8p]
     L.relmc_db_import.restype = C.c_int32
+    if hasattr(L, "relmc_debug_screen_states"):
+        L.relmc_debug_screen_states.argtypes = [vp, u8p, dp, C.c_int64, u8p]
+        L.relmc_debug_screen_states.restype = C.c_int32
     if hasattr(L, "relmc_debug_set"):
         L.relmc_debug_set.argtypes = [vp, C.c_char_p, C.c_int32]
         L.relmc_debug_set.restype = C.c_int32

@@ -33,7 +33,8 @@ class RelmcError(RuntimeError):
 
 def mpoption(singular_policy: int = REFERENCE_EMULATE, **overrides) -> _abi.SolverOpts:
     """Solver options = what nsqMain.m:185-186 asks MATPOWER for (DC model, MIPS, flow limits on),
-    i.e. MIPS defaults: feastol 5e-6, gradtol/comptol/costtol 1e-6, max_it 150."""
+    i.e. MIPS defaults: feastol 5e-6, gradtol/comptol/costtol 1e-6, max_it 150.  screen=1 turns the zero-curtailment pre-screen on
+    (include/relmc.h: states with a proven LP optimum of 0 are counted, not solved; every output but the iteration statistics unchanged)."""
     o = _abi.default_solver_opts(singular_policy)
     for k, v in overrides.items():
         if not hasattr(o, k):
@@ -61,6 +62,7 @@ class NsqResult:
     n_singular: int
     n_infeasible: int
     n_nonconverged: int
+    n_screened: int                 # samples the zero-curtailment pre-screen counted without solving (mpoption(screen=1); 0 otherwise)
     elapsed_time: float
     kernel_seconds: float
     acc: _abi.Acc = field(repr=False, default=None)
@@ -273,6 +275,17 @@ class Engine:
                     "relmc_debug_mc_simulation_dense")
         return dns, nodal, dict(status=status, iters=iters)
 
+    def screen_states(self, component_states, load_scale=None) -> np.ndarray:
+        """Test hook: the zero-curtailment certificate of the pre-screen (mpoption(screen=1), relmc_screen.hip) for given states, optionally at
+        per-state load scale factors (the sequential track's hours).  Returns bool[n]: True = the pre-screen would count this state without solving it."""
+        st = np.ascontiguousarray(np.asarray(component_states).reshape(-1, self.case.ncomp) != 0, dtype=np.uint8)
+        n = st.shape[0]
+        out = np.zeros(n, dtype=np.uint8)
+        sc = None if load_scale is None else np.ascontiguousarray(np.broadcast_to(np.asarray(load_scale, dtype=np.float64), (n,)))
+        self._check(self.L.relmc_debug_screen_states(self._h, st.ctypes.data_as(_abi.c_uint8_p), None if sc is None else sc.ctypes.data_as(_abi.c_double_p), n,
+                                                     out.ctypes.data_as(_abi.c_uint8_p)), "relmc_debug_screen_states")
+        return out.astype(bool)
+
     def mc_simulation_dev(self, states_ptr: int, n: int, dns_ptr: int, nodal_ptr: int = 0,
                           status_ptr: int = 0, iters_ptr: int = 0, mpopt=None):
         """Same with every buffer already in this GPU's HBM (raw device addresses, e.g. tensor.data_ptr())."""
@@ -439,7 +452,7 @@ class Engine:
             nodal_eens=np.array(res.idx.nodal_eens[:nb]), comp_importance=np.array(res.idx.comp_importance[:nc]),
             beta_history=hist[0][:k], edns_history=hist[1][:k], lole_history=hist[2][:k], plc_history=hist[3][:k],
             converged=bool(res.converged), mean_iters=res.idx.mean_iters, n_singular=int(res.acc.n_singular),
-            n_infeasible=int(res.acc.n_infeasible), n_nonconverged=int(res.acc.n_nonconverged),
+            n_infeasible=int(res.acc.n_infeasible), n_nonconverged=int(res.acc.n_nonconverged), n_screened=int(res.acc.n_screened),
             elapsed_time=res.wall_seconds, kernel_seconds=res.kernel_seconds, acc=res.acc,
             samples_per_batch=int(samples_per_batch), beta_limit=float(beta_limit),
             database_row_count=self.db_size()[0] if mode == 2 else None, hours_per_year=float(hours_per_year), _ng=self.case.ng)

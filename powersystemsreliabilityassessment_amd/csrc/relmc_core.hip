@@ -111,6 +111,7 @@ int launch_eval_mode(relmc_ctx* ctx, int mode, EvalArgs& a, int* rows_out, hipEv
         case 4: return launch_eval_t<4, TL>(ctx, a, rows_out, e0, e1, alt);
         case 5: return launch_eval_t<5, TL>(ctx, a, rows_out, e0, e1, alt);
         case 6: return launch_eval_t<6, TL>(ctx, a, rows_out, e0, e1, alt);
+        case 7: return launch_eval_t<7, TL>(ctx, a, rows_out, e0, e1, alt);
         default: return fail(ctx, RELMC_ERR_INVALID, "launch_eval: unknown mode");
     }
 }
@@ -122,7 +123,7 @@ int eval_set_lds(relmc_ctx* ctx, int bytes)
     for (const void* f : {reinterpret_cast<const void*>(&relmc_eval_kernel<0, TL>), reinterpret_cast<const void*>(&relmc_eval_kernel<1, TL>),
                           reinterpret_cast<const void*>(&relmc_eval_kernel<2, TL>), reinterpret_cast<const void*>(&relmc_eval_kernel<3, TL>),
                           reinterpret_cast<const void*>(&relmc_eval_kernel<4, TL>), reinterpret_cast<const void*>(&relmc_eval_kernel<5, TL>),
-                          reinterpret_cast<const void*>(&relmc_eval_kernel<6, TL>)})
+                          reinterpret_cast<const void*>(&relmc_eval_kernel<6, TL>), reinterpret_cast<const void*>(&relmc_eval_kernel<7, TL>)})
         HIP_TRY(ctx, hipFuncSetAttribute(f, hipFuncAttributeMaxDynamicSharedMemorySize, bytes));
     return RELMC_OK;
 }
@@ -327,6 +328,7 @@ void relmc_ctx_destroy(relmc_ctx* ctx)
     for (void* p : {ctx->dcase_alt[0], ctx->dcase_alt[1]}) if (p) (void)hipFree(p);
     retry_free(ctx);
     seq_free(ctx);
+    screen_free(ctx);
     comm_free(ctx);
     pipe_free(ctx);
     memo_free(ctx);
@@ -393,13 +395,15 @@ int32_t relmc_case_load(relmc_ctx* ctx, const relmc_case_desc* d)
     // smallest tile that holds the case: 16-lane rows (four scenarios per wavefront) or one scenario per wavefront
     if (fits_tile24(d)) {
         ctx->tile = 0;
-        const int rc = case_load_impl<Tile24>(ctx, d, ctx->hcase24);
+        int rc = case_load_impl<Tile24>(ctx, d, ctx->hcase24);
         ctx->order_hint.clear();                         // a hint is for one relmc_case_load
+        if (rc == RELMC_OK) rc = screen_build(ctx, d);
         return rc ? rc : order_calibrate(ctx);
     }
     ctx->tile = 1;
-    const int rc = case_load_impl<Tile96>(ctx, d, ctx->hcase96);
+    int rc = case_load_impl<Tile96>(ctx, d, ctx->hcase96);
     ctx->order_hint.clear();
+    if (rc == RELMC_OK) rc = screen_build(ctx, d);
     return rc ? rc : order_calibrate(ctx);
 }
 

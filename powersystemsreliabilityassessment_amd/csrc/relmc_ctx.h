@@ -10,6 +10,7 @@
 //   relmc_database.hip   the reference's dedupe and persistent unique-state database on the device
 //   relmc_comm.hip       the path's single collective: RCCL (bound at run time) or a host-supplied all-reduce, with a wall-clock guard
 //   relmc_seq.hip        sequential track (chronology, scaled-load hours, annual indices, the seqMain loop) and the HL1 copper sheet
+//   relmc_screen.hip     the zero-curtailment pre-screen (relmc_solver_opts.screen): certificate tables, pre-pass kernels, worklists
 //   relmc_debug.hip      introspection and test hooks that are not part of include/relmc.h
 #pragma once
 #include <hip/hip_runtime.h>
@@ -110,6 +111,14 @@ struct relmc_ctx {
     // HL1 copper-sheet model
     bool has_hl1 = false; relmc::Hl1Case* dhl1 = nullptr; double* dsorted = nullptr; double* dsuffix = nullptr; int hl1_hours = 0;
     double* h1_lole = nullptr; double* h1_eue = nullptr; int64_t h1_cap = 0; double* h1_part = nullptr; int64_t h1_part_cap = 0;   // relmc_hl1_nsq's device buffers, grow-only
+    // zero-curtailment pre-screen (relmc_screen.hip): certificate tables of the case (device pointers inside tab), grow-only work buffers of a pre-pass
+    struct Screen {
+        relmc::ScreenTab tab = {};
+        void* dtab = nullptr;
+        uint32_t* keys = nullptr; uint8_t* flags = nullptr; uint32_t* idx = nullptr; uint32_t* dcount = nullptr; void* tmp = nullptr;
+        size_t tmp_bytes = 0; int64_t cap = 0;
+        hipEvent_t ev0 = nullptr, ev1 = nullptr;
+    } screen;
     double last_kernel_ms = 0.0;
     long conflict_before = 0, conflict_after = 0;   // modelled extra LDS cycles per Newton step before / after the placement search
     long alt_conflict_before[kAlt] = {0, 0}, alt_conflict_after[kAlt] = {0, 0};      // the same of the further orders' images
@@ -198,5 +207,14 @@ int comm_allreduce_f64(relmc_ctx* ctx, double* buf, int64_t count);
 
 // ---- relmc_seq.hip ------------------------------------------------------------------------------------------------------------
 void seq_free(relmc_ctx* ctx);
+
+// ---- relmc_screen.hip ---------------------------------------------------------------------------------------------------------
+void screen_free(relmc_ctx* ctx);
+int screen_build(relmc_ctx* ctx, const relmc_case_desc* d);          // relmc_case_load: PTDF / LODF tables of the certificate
+// samples [first_index, first_index + m): masks of the uncovered ones in ctx->screen.keys (own position), their ascending positions in ctx->screen.idx
+int screen_prepass_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m, uint32_t* n_surv, double* ms);
+int screen_prepass_rows(relmc_ctx* ctx, int64_t first, int64_t n, uint32_t* n_surv);      // new database rows: certified ones filled in, the others listed
+int screen_seq_compact(relmc_ctx* ctx, const uint32_t* masks, int n_years, uint16_t* hours, uint32_t* counts, uint32_t* ncont);
+constexpr int64_t kScreenChunk = (int64_t)1 << 22;                   // samples per pre-pass of the fused path (its buffers: 4 OW + 5 bytes per sample)
 
 }  // namespace relmc_host

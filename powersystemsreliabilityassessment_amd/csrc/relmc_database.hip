@@ -305,17 +305,27 @@ int db_batch_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n
             EvalArgs a = make_args(o);
             a.n = (int64_t)n_new; a.memo_keys = ctx->db_keys; a.db_first = ctx->db_n;
             a.dns = ctx->db_dns; a.status = ctx->db_meta; a.nodal = ctx->db_nodal;
+            // screen = 1 (relmc_screen.hip): the new rows the zero-curtailment certificate covers get their (0, zeros) right away, the interior
+            // point runs over the list of the others
+            if (o.screen != 0 && ctx->screen.tab.valid != 0) {
+                uint32_t n_eval = 0;
+                rc = screen_prepass_rows(ctx, ctx->db_n, (int64_t)n_new, &n_eval);
+                if (rc) return rc;
+                a.n = (int64_t)n_eval; a.memo_perm = ctx->screen.idx;
+            }
             int rows = 0;
-            rc = fail_arm(ctx, a, 0, true, a.n);
-            if (rc) return rc;
-            rc = launch_eval(ctx, 4, a, &rows);
-            if (rc) return rc;
-            rc = finish_timing(ctx);
-            if (rc) return rc;
-            eval_ms = ctx->last_kernel_ms;
             RetryOut ro;
-            rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &eval_ms);
-            if (rc) return rc;
+            if (a.n > 0) {
+                rc = fail_arm(ctx, a, 0, true, a.n);
+                if (rc) return rc;
+                rc = launch_eval(ctx, 4, a, &rows);
+                if (rc) return rc;
+                rc = finish_timing(ctx);
+                if (rc) return rc;
+                eval_ms = ctx->last_kernel_ms;
+                rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &eval_ms);
+                if (rc) return rc;
+            }
             for (size_t r = 0; r < ro.rec.size(); ++r) {          // into the rows the first attempt filled
                 const size_t row = (size_t)ctx->db_n + (size_t)ro.rec[r].unit, nbz = (size_t)ctx->nb;
                 HIP_TRY(ctx, hipMemcpy(ctx->db_dns + row, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice));

@@ -148,7 +148,9 @@ struct EvalArgs {
     const uint32_t* memo_perm;      // [n] sample indices sorted by mask
     const uint32_t* memo_start;     // [n_distinct + 1] first sorted position of every distinct mask
     // MODE 4 (rows of the persistent state database): scenario u = row db_first + u, key words at memo_keys[row][OW],
-    // results go to dns[row], status[row] (packed) and nodal[row][nb]
+    // results go to dns[row], status[row] (packed) and nodal[row][nb].  Behind the zero-curtailment pre-screen memo_perm lists the new rows the
+    // certificate did not cover: scenario u = row db_first + memo_perm[u] (null = all rows)
+    // MODE 7 (fused path behind the pre-screen): scenario u = sample memo_perm[u] of the range, state memo_keys[memo_perm[u]][OW]
     int64_t db_first;
     // Units (samples / states / rows) that end non-converged (status 1 or 2) are listed here instead of being accumulated; the host
     // evaluates them again under further elimination orders (relmc_retry.hip: fail_retry).  Null = off.
@@ -159,6 +161,25 @@ struct EvalArgs {
     // MODE 6 (dense pivoted last resort): [scenario rows of the grid][dense_stride] doubles of global scratch, dense_stride >= 2 nb (2 nb + 1)
     double* dense;
     uint64_t dense_stride;
+};
+
+// Zero-curtailment certificate (relmc_screen.hip; SURVEY 8f rank 4, mc_simulation.m:57-59, 65): tables built by relmc_case_load on the host, resident in
+// HBM, read through the vector-memory path.  A state is certified when the units in service, loaded proportionally between Pmin and Pmax,
+// serve the whole load with every DC flow inside its rating: base-topology PTDF, one line out through its LODF column, more lines out never.
+struct ScreenTab {
+    int32_t nl, ng, valid, pad;
+    double total_load;              // MW at load scale 1
+    double sum_pmin, sum_rng;       // MW over all units: sum Pmin, sum (Pmax - Pmin)
+    const double* pmin;             // [ng] MW
+    const double* rng;              // [ng] MW, Pmax - Pmin
+    const double* f_min;            // [nl] MW flow of (all units at Pmin) through the PTDF
+    const double* f_rng;            // [nl] MW flow of (all units' ranges)
+    const double* f_load;           // [nl] MW flow of the bus loads at scale 1 (positive = the loads' own contribution, subtracted)
+    const double* lim;              // [nl] MW rating shrunk by the safety margin; +inf = no limit
+    const double* gmin;             // [nl][ng] PTDF[l, bus(k)] * Pmin_k
+    const double* grng;             // [nl][ng] PTDF[l, bus(k)] * (Pmax_k - Pmin_k)
+    const double* lodf;             // [nl (line out m)][nl] flow change on l per MW of pre-outage flow on m; lodf[m][m] = -1
+    const uint8_t* bridge;          // [nl] 1 = taking the line out splits the network: never certified
 };
 
 // device image of relmc_acc (include/relmc.h): 6 + 256 + 1 int64, then 2 + 128 doubles

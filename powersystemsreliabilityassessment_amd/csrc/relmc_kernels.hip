@@ -74,6 +74,8 @@ constexpr int kPfMaskWide = 0xc6;    // 64-lane tile: sites 1, 2, 6, 7 (-2.9 %)
 // MODE 4: new rows of the persistent state database (nsqMain.m:257-278): scenario u = database row db_first + u, state from
 //         the row's key words, results written into the row (dns, status/iterations, nodal shed); no accumulation
 // MODE 6: MODE 4 with a dense, partially pivoted Newton solve in global scratch (a.dense): the last resort of the retry path
+// MODE 7: the fused path behind the zero-curtailment pre-screen (relmc_screen.hip): scenario u = sample memo_perm[u] of the launch's range, the
+//         ones the certificate did not cover, state = memo_keys[memo_perm[u]]; accumulators as MODE 0, per-sample dns at the sample's own index
 template <int MODE_, class TL>
 __global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(const DevCaseT<TL>* __restrict__ gcase, const EvalArgs a)
 {
@@ -314,8 +316,10 @@ __global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(con
                 wgt = a.memo_start[sidx + 1] - s0;
                 if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)a.memo_perm[s0] * OW + rlane];
             } else if (MODE == 4) {
-                if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)(a.db_first + sidx) * OW + rlane];
+                if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)(a.db_first + (a.memo_perm ? (int64_t)a.memo_perm[sidx] : sidx)) * OW + rlane];
                 if (a.load_scale) lscale = a.load_scale[sidx];          // retry rows of the scaled-load entry point
+            } else if (MODE == 7) {
+                if (rlane < OW) OB[rlane] = a.memo_keys[(size_t)a.memo_perm[sidx] * OW + rlane];
             } else {
                 if (rlane < OW) OB[rlane] = 0u;
                 RELOAD_FENCE();
@@ -1230,7 +1234,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(con
                     if (rlane < OW) fr->mask[rlane] = OB[rlane];
                     if (rlane == 0) {
                         const int64_t u = (MODE == 0 && WINDOWED) ? wb * 4 + WINL[wg * 4 + lane / RW]
-                                          : (MODE == 2 ? (int64_t)seq_year * a.seq_hpy + seq_hour : sidx);      // MODE 2: the hour of the chronology
+                                          : (MODE == 2 ? (int64_t)seq_year * a.seq_hpy + seq_hour                // MODE 2: the hour of the chronology
+                                          : (MODE == 7 ? (int64_t)a.memo_perm[sidx]                              // MODE 7: the sample's offset in the range
+                                          : (MODE == 4 && a.memo_perm ? (int64_t)a.memo_perm[sidx] : sidx)));      // MODE 4 behind the pre-screen: the row's offset
                         fr->unit = (unsigned long long)(u + a.unit_base); fr->weight = wgt; fr->pad = 0;
                     }
                 }
@@ -1265,8 +1271,9 @@ __global__ void __launch_bounds__(64 * TL::WPB, kMinWaves) relmc_eval_kernel(con
             if (MODE == 2 && rlane == 0) a.curt[(size_t)seq_year * a.seq_hpy + seq_hour] = dns;
             if (MODE == 0 && a.dns && rlane == 0)      // optional: dns of every sample in sampling order (checkpoint histories of small batches)
                 a.dns[WINDOWED ? wb * 4 + WINL[wg * 4 + lane / RW] : sidx] = dns;
+            if (MODE == 7 && a.dns && rlane == 0) a.dns[a.memo_perm[sidx]] = dns;
             if (MODE == 1 || MODE == 4) {
-                const int64_t oidx = MODE == 4 ? a.db_first + sidx : sidx;       // MODE 4: the database row
+                const int64_t oidx = MODE == 4 ? a.db_first + (a.memo_perm ? (int64_t)a.memo_perm[sidx] : sidx) : sidx;       // MODE 4: the database row
 #pragma unroll
                 for (int s = 0; s < IS; ++s) if (RW * s + rlane < nip) IR[4 * (RW * s + rlane)] = shed[s];
                 if (rlane == 0) {

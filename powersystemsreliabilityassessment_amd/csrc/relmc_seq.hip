@@ -126,7 +126,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     if (alloc_ok && ctx->sq_years < n_years) {
         for (void* q : {(void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year}) if (q) (void)hipFree(q);
         ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr; ctx->sq_years = 0;
-        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * n_years) == hipSuccess && hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
+        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * 2 * n_years) == hipSuccess &&     // [0, n): listed hours per year, [cap, cap + n): contingency hours (pre-screen) hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
                    hipMalloc(&ctx->sq_year, sizeof(double) * 3 * n_years) == hipSuccess;
         if (alloc_ok) ctx->sq_years = n_years;
     }
@@ -136,13 +136,24 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     auto cleanup = [&]() {};
     int rc = seq_sample(ctx, seed, first_year, n_years, &dm);
     if (rc) return rc;
-    std::vector<uint32_t> counts(n_years), off(n_years + 1, 0);
+    std::vector<uint32_t> counts(n_years), ncont(n_years), off(n_years + 1, 0);
     bool ok = hipMemsetAsync(dcurt, 0, nh * sizeof(double), ctx->stream) == hipSuccess;
-    hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, ctx->hseq.mw, dhours, dcounts);
+    // screen = 1 (relmc_screen.hip): the contingency hours are counted as before, but only the ones the zero-curtailment certificate does not cover
+    // -- at the hour's own load factor -- are listed for the interior point; a covered hour's curtailment stays the 0 it was set to above
+    const bool screen = o.screen != 0 && ctx->screen.tab.valid != 0;
+    uint32_t* const dncont = dcounts + ctx->sq_years;
+    if (screen) ok = ok && screen_seq_compact(ctx, dm, n_years, dhours, dcounts, dncont) == RELMC_OK;
+    else hipLaunchKernelGGL(relmc_seq_compact_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dm, hpy, ctx->hseq.mw, dhours, dcounts);
     ok = ok && hipGetLastError() == hipSuccess && hipMemcpyAsync(counts.data(), dcounts, sizeof(uint32_t) * n_years, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess &&
+         (!screen || hipMemcpyAsync(ncont.data(), dncont, sizeof(uint32_t) * n_years, hipMemcpyDeviceToHost, ctx->stream) == hipSuccess) &&
          hipStreamSynchronize(ctx->stream) == hipSuccess;
     if (!ok) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: compaction failed"); }
-    for (int y = 0; y < n_years; ++y) { off[y + 1] = off[y] + counts[y]; years_out[y].n_contingency = counts[y]; }
+    int64_t certified = 0;
+    for (int y = 0; y < n_years; ++y) {
+        off[y + 1] = off[y] + counts[y];
+        years_out[y].n_contingency = screen ? ncont[y] : counts[y];
+        if (screen) certified += (int64_t)ncont[y] - (int64_t)counts[y];
+    }
     const int64_t nlp = off[n_years];
     double ms = 0.0;
     if (nlp > 0) {
@@ -173,6 +184,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
             if (hipMemcpy(dcurt + ro.rec[r].unit, &ro.dns[r], sizeof(double), hipMemcpyHostToDevice) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
         }
     }
+    acc_out->n += certified; acc_out->n_screened += certified;
     hipLaunchKernelGGL(relmc_seq_annual_kernel, dim3(n_years), dim3(256), 0, ctx->stream, dcurt, hpy, curtail_threshold, dyear);
     std::vector<double> yr((size_t)3 * n_years);
     if (hipGetLastError() != hipSuccess || hipMemcpyAsync(yr.data(), dyear, sizeof(double) * 3 * n_years, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||

@@ -141,20 +141,33 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     // a wavefront row counts its scenarios in 32 bits: split very large ranges
-    const int64_t kMaxPerLaunch = (int64_t)1 << 31;
+    // screen = 1 (relmc_screen.hip): a pre-pass draws the masks and runs the zero-curtailment certificate, one thread per sample; only the samples it
+    // does not cover are solved (MODE 7, from the stored masks, in ascending sample order), the others add 1 to n and to n_screened
+    const bool screen = o.screen != 0 && ctx->screen.tab.valid != 0;
+    const int64_t kMaxPerLaunch = screen ? kScreenChunk : (int64_t)1 << 31;
     double ms_total = 0.0;
     for (int64_t done = 0; done < n;) {
         const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
         EvalArgs a = make_args(o);
         a.seed = seed; a.first_index = first_index + (uint64_t)done; a.n = m;
         a.dns = dns_dev ? dns_dev + done : nullptr;
+        int64_t certified = 0;
+        if (screen) {
+            uint32_t ns = 0;
+            if (dns_dev) HIP_TRY(ctx, hipMemsetAsync(dns_dev + done, 0, sizeof(double) * (size_t)m, ctx->stream));
+            const int rc0 = screen_prepass_nsq(ctx, seed, first_index + (uint64_t)done, m, &ns, &ms_total);
+            if (rc0) return rc0;
+            certified = m - (int64_t)ns;
+            a.n = (int64_t)ns; a.memo_keys = ctx->screen.keys; a.memo_perm = ctx->screen.idx;
+        }
         int blocks = 0;
         relmc_acc part;
+        relmc_acc_zero(&part);
         uint32_t listed = 0;
-        for (int attempt = 0;; ++attempt) {
+        for (int attempt = 0; a.n > 0; ++attempt) {
             int rc = fail_arm(ctx, a, done, true, m);
             if (rc) return rc;
-            rc = launch_eval(ctx, 0, a, &blocks);
+            rc = launch_eval(ctx, screen ? 7 : 0, a, &blocks);
             if (rc) return rc;
             rc = launch_finalize(ctx, blocks);
             if (rc) return rc;
@@ -174,9 +187,10 @@ int nsq_accumulate_impl(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int
             rc = fail_list_ensure(ctx, listed + listed / 8 > kFailCapMax ? kFailCapMax : listed + listed / 8);
             if (rc) return rc;
         }
+        part.n += certified; part.n_screened += certified;
         int rc = RELMC_OK;
         RetryOut ro;
-        rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total, a.fail_count ? &listed : nullptr);
+        if (a.n > 0) rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total, a.fail_count ? &listed : nullptr);
         if (rc) return rc;
         for (size_t r = 0; r < ro.rec.size(); ++r) {
             acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);

@@ -24,7 +24,7 @@ def funcs(path):
             if ln.startswith(".Lfunc_end"):
                 out[cur] = buf; cur = None
             elif not ln.strip().startswith((";", ".")):
-                buf.append(re.sub(r";.*", "", ln).strip())
+                buf.append(re.sub(r"\.LBB\d+_", ".LBB_", re.sub(r";.*", "", ln)).strip())      # block labels carry the function's ordinal in the unit
     return out
 
 
