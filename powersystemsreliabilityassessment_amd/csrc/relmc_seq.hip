@@ -126,7 +126,8 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     if (alloc_ok && ctx->sq_years < n_years) {
         for (void* q : {(void*)ctx->sq_counts, (void*)ctx->sq_off, (void*)ctx->sq_year}) if (q) (void)hipFree(q);
         ctx->sq_counts = ctx->sq_off = nullptr; ctx->sq_year = nullptr; ctx->sq_years = 0;
-        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * 2 * n_years) == hipSuccess &&     // [0, n): listed hours per year, [cap, cap + n): contingency hours (pre-screen) hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
+        // sq_counts: [0, n) listed hours per year, [cap, cap + n) contingency hours per year (pre-screen)
+        alloc_ok = hipMalloc(&ctx->sq_counts, sizeof(uint32_t) * 2 * n_years) == hipSuccess && hipMalloc(&ctx->sq_off, sizeof(uint32_t) * (n_years + 1)) == hipSuccess &&
                    hipMalloc(&ctx->sq_year, sizeof(double) * 3 * n_years) == hipSuccess;
         if (alloc_ok) ctx->sq_years = n_years;
     }

@@ -1,0 +1,259 @@
+"""The zero-curtailment pre-screen (relmc_solver_opts.screen = 1, csrc/relmc_screen.hip).
+
+Soundness rests on mc_simulation.m:57-59 (dns < 0.1 -> 0) and :65 (nodal shed only when dns > 0): a state with a proven LP optimum of zero
+curtailment has the outputs (0, zeros) whatever the interior point does.  What is tested:
+  CPU  the host model of the certificate (tests/tools/screen_model.py) issues no false certificate against the C oracle -- fixtures, sampled
+       states, sequential hours at their load factors, the random networks of test_random_cases.py;
+  GPU  the device's certificate equals the model's state by state; with screen = 1 every accumulator but the iteration sum (and n_screened)
+       equals screen = 0 -- integers exactly, fp64 sums to summation order -- on 2e6 RTS-24 / 3e5 RTS-96 samples under both policies, on the
+       per-sample dns behind the checkpoint histories, on the state database's rows, on 125 sequential years and on the random networks.
+"""
+import importlib.util
+import os
+
+import numpy as np
+import pytest
+
+from powersystemsreliabilityassessment_amd import _abi, api, case96, loadcurve, seq
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _load(name, rel):
+    spec = importlib.util.spec_from_file_location(name, os.path.join(ROOT, rel))
+    m = importlib.util.module_from_spec(spec); spec.loader.exec_module(m)
+    return m
+
+
+@pytest.fixture(scope="module")
+def model():
+    return _load("screen_model", "tests/tools/screen_model.py")
+
+
+@pytest.fixture(scope="module")
+def case96_():
+    return case96.rts96()
+
+
+@pytest.fixture(scope="module")
+def oracle96(case96_):
+    from oracle import coracle
+    return coracle.Oracle(case96_)
+
+
+# ---------------------------------------------------------------------------------------------- CPU: the model against the oracle
+def test_model_certificate_is_sound_on_rts24(case, oracle, model, states_fixture):
+    ptdf, lodf = model.tables(case)
+    # flows of the intact system at peak load, all units on, proportional dispatch: inside every rating (the base case is certified)
+    assert model.certify(case, ptdf, lodf, np.zeros((1, case.ncomp), dtype=np.uint8))[0]
+    # line 11 (bus 7 - bus 8) is RTS-24's only bridge; its outage is never certified
+    assert np.flatnonzero(np.isnan(lodf[0])).tolist() == [10]
+    st = states_fixture["matrix"]
+    for pol in (_abi.RELMC_REFERENCE_EMULATE, _abi.RELMC_PHYSICAL):
+        ref = oracle.mc_simulation(st, pol, nthreads=8)
+        cert = model.certify(case, ptdf, lodf, st)
+        assert not np.any(cert & (ref["dns"] != 0)) and not np.any(cert & (ref["status"] != 0)) and not np.any(cert & (ref["relaxed"] != 0))
+    d = oracle.nsq_database(1, beta_limit=0.0, max_iterations=400_000, samples_per_batch=100_000, nthreads=8)
+    cert = model.certify(case, ptdf, lodf, d["states"])
+    c = d["count"].astype(float)
+    assert not np.any(cert & (d["dns"] != 0)) and not np.any(cert & (d["status"] != 0)) and not np.any(cert & (d["relaxed"] != 0))
+    share, of_zero = c[cert].sum() / c.sum(), c[cert].sum() / c[d["dns"] == 0].sum()
+    print(f"\nRTS-24 certificate: {share:.4f} of 4e5 samples, {of_zero:.4f} of the zero-curtailment ones")
+    assert 0.89 < share < 0.92 and of_zero > 0.98
+    # base topology only (what VERDICT r5 probed): 85 %
+    base = model.certify(case, ptdf, lodf, d["states"], max_lines_out=0)
+    assert 0.84 < c[base].sum() / c.sum() < 0.87 and not np.any(base & ~cert)
+
+
+def test_model_certificate_is_sound_on_sequential_hours(case, oracle, model):
+    """Contingency hours of three simulated years at their own load factors (seqMain.m:97-133): 99 % certified, none falsely."""
+    ptdf, lodf = model.tables(case)
+    rel = seq.seqmeantime(); lf = loadcurve.anloducurve(8736)[2]
+    n_cert = n_cont = 0
+    for y in range(3):
+        st = oracle.seq_mcsampling(rel, 8736, 1, y, 1)
+        hrs = np.flatnonzero(st.any(1))
+        r = oracle.seq_mcsimulation(st[hrs], lf[hrs], nthreads=8)
+        cert = model.certify(case, ptdf, lodf, st[hrs], load_scale=lf[hrs])
+        assert not np.any(cert & (r["dns"] != 0)) and not np.any(cert & (r["relaxed"] != 0))
+        n_cert += int(cert.sum()); n_cont += hrs.size
+    assert n_cert / n_cont > 0.96          # 0.979 on these three years, 0.992 over twenty (tests/tools/screen_model.py seq 20)
+
+
+def test_model_certificate_is_sound_on_random_networks(model):
+    """The random networks of test_random_cases.py (2 ... 100 buses; double circuits, unlimited branches, Pmin > 0, forced-up components):
+    no certified state sheds load in the oracle."""
+    from oracle import coracle
+    trc = _load("trc", "tests/test_random_cases.py")
+    tot = cert_tot = 0
+    for spec in trc.CASES:
+        seed, nb, chords, ng, lbs, tight, par, pminf = spec
+        case = trc.random_case(np.random.default_rng(1000 + seed), nb, chords, ng, lbs, tight, par, pminf)
+        orc = coracle.Oracle(case)
+        n = 1500 if nb <= 32 else 400
+        st = orc.mc_sampling(seed, 0, n)
+        ref = orc.mc_simulation(st, _abi.RELMC_PHYSICAL, nthreads=8)
+        ptdf, lodf = model.tables(case)
+        cert = model.certify(case, ptdf, lodf, st)
+        assert not np.any(cert & (ref["dns"] != 0)), spec
+        tot += n; cert_tot += int(cert.sum())
+    assert cert_tot > 0.2 * tot
+
+
+# ---------------------------------------------------------------------------------------------- GPU
+def _split(acc):
+    """(integers that must be identical, iteration sum, n_screened, doubles)"""
+    ai, ad = acc.to_arrays()
+    return np.concatenate([ai[:5], ai[6:-1]]), int(ai[5]), int(ai[-1]), ad
+
+
+@pytest.mark.gpu
+def test_device_certificate_equals_the_model(engine, oracle, model, states_fixture, case):
+    ptdf, lodf = model.tables(case)
+    st = np.vstack([states_fixture["matrix"], oracle.mc_sampling(9, 0, 60_000)])
+    dev = engine.screen_states(st)
+    mod = model.certify(case, ptdf, lodf, st)
+    assert np.array_equal(dev, mod) and 0.85 < dev[len(states_fixture["matrix"]):].mean() < 0.93
+    ref = oracle.mc_simulation(states_fixture["matrix"], _abi.RELMC_REFERENCE_EMULATE, nthreads=8)
+    assert not np.any(dev[:len(ref["dns"])] & (ref["dns"] != 0))
+    # at load scale factors (the sequential track's hours)
+    rng = np.random.default_rng(4)
+    sc = rng.uniform(0.3, 1.0, st.shape[0])
+    assert np.array_equal(engine.screen_states(st, sc), model.certify(case, ptdf, lodf, st, load_scale=sc))
+    assert engine.screen_states(st[:0]).shape == (0,)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_screened_accumulate_equals_unscreened_rts24_2e6(engine, policy, capsys):
+    n = 2_000_000
+    a = engine.nsq_accumulate(3, 10**9, n, api.mpoption(policy)); ta = engine.last_kernel_ms()
+    b = engine.nsq_accumulate(3, 10**9, n, api.mpoption(policy, screen=1)); tb = engine.last_kernel_ms()
+    ia, ita, sa, da = _split(a); ib, itb, sb, db = _split(b)
+    assert np.array_equal(ia, ib) and sa == 0 and 0.89 * n < sb < 0.92 * n and itb < 0.15 * ita
+    np.testing.assert_allclose(db, da, rtol=1e-13, atol=0)
+    assert a.n == b.n == n and a.n_nonconverged == b.n_nonconverged == 0
+    with capsys.disabled():
+        print(f"\n   pre-screen RTS-24 policy {policy}: {sb / n:.4f} of 2e6 samples certified, {ta:.2f} -> {tb:.2f} ms", end="")
+    # a range that is all certificates but a handful, a range of one sample, an empty range
+    c0, c1 = engine.nsq_accumulate(3, 5, 1, api.mpoption(policy)), engine.nsq_accumulate(3, 5, 1, api.mpoption(policy, screen=1))
+    assert np.array_equal(_split(c0)[0], _split(c1)[0]) and c1.n == 1
+    assert engine.nsq_accumulate(3, 5, 0, api.mpoption(policy, screen=1)).n == 0
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
+def test_screened_accumulate_equals_unscreened_rts96_3e5(case96_, policy, capsys):
+    eng = api.Engine(case96_)
+    try:
+        n = 300_000
+        a = eng.nsq_accumulate(1, 0, n, api.mpoption(policy)); ta = eng.last_kernel_ms()
+        b = eng.nsq_accumulate(1, 0, n, api.mpoption(policy, screen=1)); tb = eng.last_kernel_ms()
+        ia, ita, sa, da = _split(a); ib, itb, sb, db = _split(b)
+        assert np.array_equal(ia, ib) and sa == 0 and 0.96 * n < sb < 0.98 * n
+        np.testing.assert_allclose(db, da, rtol=1e-13, atol=0)
+        with capsys.disabled():
+            print(f"\n   pre-screen RTS-96 policy {policy}: {sb / n:.4f} of 3e5 samples certified, {ta:.2f} -> {tb:.2f} ms", end="")
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_device_certificate_is_sound_on_rts96(case96_, oracle96, model):
+    eng = api.Engine(case96_)
+    try:
+        st = oracle96.mc_sampling(2, 0, 20_000)
+        dev = eng.screen_states(st)
+        ptdf, lodf = model.tables(case96_)
+        assert np.array_equal(dev, model.certify(case96_, ptdf, lodf, st))
+        ref = oracle96.mc_simulation(st, _abi.RELMC_REFERENCE_EMULATE, nthreads=16)
+        assert not np.any(dev & (ref["dns"] != 0)) and not np.any(dev & (ref["status"] != 0)) and dev.mean() > 0.95
+    finally:
+        eng.close()
+
+
+@pytest.mark.gpu
+def test_screened_checkpoint_histories_and_stopping_point(engine):
+    """relmc_nsq_run at the reference's checkpoint spacing of 100 (nsqMain.m:60): the per-sample dns behind the histories is the unscreened
+    run's, so the loop stops at the same checkpoint with the same histories."""
+    for limit, cap in ((0.01, 400_000), (0.0, 150_000)):
+        a = engine.nsqMain(beta_limit=limit, max_iterations=cap, samples_per_batch=100, seed=1)
+        b = engine.nsqMain(beta_limit=limit, max_iterations=cap, samples_per_batch=100, seed=1, mpopt=api.mpoption(screen=1))
+        assert a.current_iteration == b.current_iteration and a.converged == b.converged and len(a.beta_history) == len(b.beta_history)
+        assert np.array_equal(a.plc_history, b.plc_history)
+        np.testing.assert_allclose(b.edns_history, a.edns_history, rtol=1e-13)
+        np.testing.assert_allclose(b.beta_history, a.beta_history, rtol=1e-10)
+        # the first stretch (24 576 samples) is the per-sample values themselves summed in sampling order on the host: bit-identical; later
+        # checkpoints start from the accumulators of the stretches before, whose fp64 sums differ in their summation order (1e-16)
+        assert np.array_equal(a.edns_history[:240], b.edns_history[:240]) and np.array_equal(a.beta_history[:240], b.beta_history[:240])
+        assert np.array_equal(_split(a.acc)[0], _split(b.acc)[0]) and b.n_screened > 0.85 * b.current_iteration and a.n_screened == 0
+    assert a.current_iteration == 150_000
+
+
+@pytest.mark.gpu
+def test_screened_database_rows(engine):
+    """The state database with the pre-screen: rows, counts, dns, flags and nodal split identical; certified rows carry 0 iterations and the
+    screened bit, n_screened is their count-weighted number."""
+    kw = dict(beta_limit=0.0, max_iterations=1_000_000, samples_per_batch=250_000, seed=2, distinct_states="database")
+    a = engine.nsqMain(**kw); ra = engine.db_export(); engine.db_reset()
+    b = engine.nsqMain(mpopt=api.mpoption(screen=1), **kw); rb = engine.db_export(); engine.db_reset()
+    assert a.database_row_count == b.database_row_count
+    for k in ("states", "count", "dns", "flag", "nodal", "status", "relaxed"):
+        assert np.array_equal(ra[k], rb[k]), k
+    assert np.array_equal(_split(a.acc)[0], _split(b.acc)[0])
+    np.testing.assert_allclose(_split(b.acc)[3], _split(a.acc)[3], rtol=1e-13)
+    skipped = rb["iters"] == 0
+    assert np.all(rb["dns"][skipped & (rb["status"] == 0)] == 0) and b.n_screened == int(rb["count"][skipped & (rb["status"] == 0)].sum())
+    assert 0.5 < skipped.mean() < 0.8 and np.array_equal(ra["iters"][~skipped], rb["iters"][~skipped])
+    assert b.n_screened > 0.88 * b.current_iteration and a.n_screened == 0
+    # a database filled without the pre-screen refuses a batch with it (results of other solver options)
+    engine.nsq_db_batch(2, 0, 1000)
+    with pytest.raises(api.RelmcError, match="other solver options"):
+        engine.nsq_db_batch(2, 1000, 1000, api.mpoption(screen=1))
+    engine.db_reset()
+
+
+@pytest.mark.gpu
+def test_screened_sequential_years(engine, capsys):
+    """125 simulated years (BASELINE configs[3] per GPU): annual (ens, dlc, nlc, contingency hours) identical, accumulators identical but
+    for the iteration sum; ~99 % of the contingency hours are certified at their own load factor."""
+    se = seq.SeqEngine(engine)
+    n = 125
+    e0, d0, l0, c0, a0 = se.seq_years(1, 0, n); t0 = engine.last_kernel_ms()
+    e1, d1, l1, c1, a1 = se.seq_years(1, 0, n, mpopt=api.mpoption(screen=1)); t1 = engine.last_kernel_ms()
+    assert np.array_equal(d0, d1) and np.array_equal(l0, l1) and np.array_equal(c0, c1)
+    np.testing.assert_allclose(e1, e0, rtol=1e-13, atol=0)
+    assert np.array_equal(e0, e1)                               # hourly curtailments summed per year in the same order
+    i0, it0, s0, dd0 = _split(a0); i1, it1, s1, dd1 = _split(a1)
+    assert np.array_equal(i0, i1) and s0 == 0 and s1 > 0.98 * a1.n and a0.n == a1.n == int(c0.sum())
+    np.testing.assert_allclose(dd1, dd0, rtol=1e-13, atol=0)
+    with capsys.disabled():
+        print(f"\n   pre-screen sequential: {s1 / a1.n:.4f} of {a1.n} contingency hours certified, {t0:.2f} -> {t1:.2f} ms per 125 years", end="")
+    r0 = se.seqMain(max_sim_years=300, cov_threshold=0.0)
+    r1 = se.seqMain(max_sim_years=300, cov_threshold=0.0, mpopt=api.mpoption(screen=1))
+    assert r0.final_year == r1.final_year == 300 and r0.eens == r1.eens and r0.lole == r1.lole and r0.lolf == r1.lolf
+    np.testing.assert_allclose(r1.nodal_eens_avg, r0.nodal_eens_avg, rtol=1e-12)
+    assert np.array_equal(r0.comp_importance, r1.comp_importance) and np.array_equal(r0.results_cum["cov"], r1.results_cum["cov"])
+
+
+@pytest.mark.gpu
+def test_screened_random_networks(model):
+    """The random networks: device certificate = model, screened accumulators = unscreened, a case whose base topology has a bridge or
+    unlimited branches included."""
+    from oracle import coracle
+    trc = _load("trc", "tests/test_random_cases.py")
+    for spec in trc.CASES:
+        seed, nb, chords, ng, lbs, tight, par, pminf = spec
+        case = trc.random_case(np.random.default_rng(1000 + seed), nb, chords, ng, lbs, tight, par, pminf)
+        eng = api.Engine(case)
+        try:
+            st = eng.mc_sampling(None, 3000, seed=seed)
+            ptdf, lodf = model.tables(case)
+            assert np.array_equal(eng.screen_states(st), model.certify(case, ptdf, lodf, st)), spec
+            for pol in (api.REFERENCE_EMULATE, api.PHYSICAL):
+                a, b = eng.nsq_accumulate(seed, 0, 20_000, api.mpoption(pol)), eng.nsq_accumulate(seed, 0, 20_000, api.mpoption(pol, screen=1))
+                ia, _, _, da = _split(a); ib, _, sb, db = _split(b)
+                assert np.array_equal(ia, ib), spec
+                np.testing.assert_allclose(db, da, rtol=1e-12, atol=1e-9)
+        finally:
+            eng.close()
