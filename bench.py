@@ -181,8 +181,9 @@ def main():
     n_dev = torch.cuda.device_count()                          # counts devices without initialising one
     if n_dev < 1:
         raise SystemExit("bench.py needs a GPU: the HIP path has no CPU fallback")
-    if world > n_dev and not args.share_device:
-        print(f"bench.py: rank {rank}: --gpus {world} but this node has {n_dev} GPU{'s' if n_dev != 1 else ''} (torch.cuda.device_count()); "
+    local_world = int(os.environ.get("LOCAL_WORLD_SIZE", world))        # ranks on THIS node (an external multi-node launcher sets it; WORLD_SIZE is global)
+    if local_world > n_dev and not args.share_device:
+        print(f"bench.py: rank {rank}: {local_world} ranks on this node (--gpus {world}) but it has {n_dev} GPU{'s' if n_dev != 1 else ''} (torch.cuda.device_count()); "
               f"--share-device puts every rank on GPU 0 (testing only)", file=sys.stderr, flush=True)
         sys.exit(EXIT_TOO_FEW_GPUS)
     if not torch.cuda.is_available():
@@ -456,7 +457,7 @@ def main():
             out["distinct_state_path"] = db_multi
         out["launcher"] = "bench.py --gpus N (self-started ranks)" if os.environ.get("RELMC_BENCH_LAUNCHER") == "bench.py" else ("external (RANK / WORLD_SIZE from the environment)" if world > 1 else "none (single rank)")
         if world > 1:
-            out["omitted"] = {"keys": ["cpu_baseline", "secondary", "sustained"] + (["time_to_cov_1pct", "distinct_state_path"] if args.workload != "nsq24" or args.no_time_to_cov else []),
+            out["omitted"] = {"keys": ["cpu_baseline", "secondary", "screened", "sustained"] + (["time_to_cov_1pct", "distinct_state_path"] if args.workload != "nsq24" or args.no_time_to_cov else []),
                               "why": "N > 1 lines are scaling rows: the CPU baseline, the other BASELINE configurations and the sustained-rate leg are measured on rank 0 at N = 1 only"}
         if world == 1 and args.workload == "nsq24" and not args.no_time_to_cov:
             # the reference checks beta every 100 samples (nsqMain.m:60, 299-312): the same spacing here (relmc_nsq_run evaluates stretches of
@@ -494,6 +495,8 @@ def main():
             out["sustained"] = sustained_rate(eng, opts, args.seed, args.sustained_samples)
         if world == 1 and args.workload == "nsq24" and not args.no_secondary:
             out["secondary"] = secondary_workloads(eng, local_rank, opts, args.seed)
+        if world == 1 and args.workload == "nsq24" and not args.no_secondary:
+            out["screened"] = screened_rates(eng, local_rank, policy, args.seed, B)
         if world == 1 and not args.no_cpu_baseline and args.workload == "nsq24":
             out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
         if args.dump_acc:
@@ -578,6 +581,64 @@ def secondary_workloads(eng24, device, opts, seed, steps=3):
                   "value": N1 / dt, "unit": "iterations/s", "ms_per_step": dt * 1e3, "kernel": "relmc_hl1_kernel", "kernel_ms_avg": kms, "steps": steps,
                   "lole_h_per_yr": float(np.mean([r.lole_hours_yr for r in rs])), "eue_mwh_per_yr": float(np.mean([r.eue_mwh_yr for r in rs])),
                   "exact_lole_eue": [9.3941, 1176.29], "includes": "per-iteration LOLE history copied to the host (the reference's convergence history, :202-204); the fleet and the load curve are loaded once"}
+    return res
+
+
+def screened_rates(eng24, device, policy, seed, B, steps=3):
+    """The same workloads with the zero-curtailment pre-screen (relmc_solver_opts.screen = 1, csrc/relmc_screen.hip), OUTSIDE the timed
+    region and never as `value`: a sample whose LP optimum is proven 0 by an explicit dispatch is counted without being solved (the reference's outputs
+    for it are (0, zeros) by mc_simulation.m:57-59, 65); every accumulator but the iteration sum equals the unscreened run's (tests/test_screen.py).
+    Wall-clocked between synchronisations like the headline: 1 warm-up + `steps` steps each."""
+    import torch
+    from powersystemsreliabilityassessment_amd import api, case96, seq as rseq
+    so = api.mpoption(policy, screen=1)
+
+    def timed(fn, eng):
+        # warm-up over the very ranges that are timed: a unit the primary elimination order does not converge on (6.7e-7 of the RTS-96 samples) makes the
+        # library build the further orders' images at first need (tens of ms, once per context) -- at 4 ms per step that would be the measurement
+        for k in range(0, steps + 1):
+            fn(k)
+        torch.cuda.synchronize()
+        t0 = time.perf_counter(); outs = []; kms = []
+        for k in range(1, steps + 1):
+            outs.append(fn(k)); kms.append(eng.last_kernel_ms())
+        torch.cuda.synchronize()
+        return outs, (time.perf_counter() - t0) / steps, sum(kms) / len(kms)
+
+    def line(accs, dt, kms, units, unit, workload):
+        n = sum(int(a.n) for a in accs); ns = sum(int(a.n_screened) for a in accs)
+        return {"workload": workload, "value": units / dt, "unit": unit, "ms_per_step": dt * 1e3, "device_ms_avg": kms, "steps": steps, "n_screened_frac": ns / max(1, n),
+                "solved_per_step": (n - ns) / len(accs), "mean_ipm_iterations_of_the_solved": sum(int(a.sum_iters) for a in accs) / max(1, n - ns),
+                "n_nonconverged": sum(int(a.n_nonconverged) for a in accs)}
+
+    res = {"what": "relmc_solver_opts.screen = 1: zero-curtailment certificate (proportional dispatch of the units in service through the base-topology PTDF, one line out "
+                   "through its LODF column) in a pre-pass, one thread per sample; only the uncovered samples reach the interior point.  Outputs other than the iteration "
+                   "statistics are those of the unscreened run (tests/test_screen.py); `value` above stays every-sample-solved"}
+    accs, dt, kms = timed(lambda k: eng24.nsq_accumulate(seed, (1 << 41) + k * B, B, so), eng24)
+    res["nsq24"] = line(accs, dt, kms, B, "scenarios/s", f"HL2 non-sequential MCS, IEEE RTS-24, {B} samples per step (BASELINE configs[1]) behind the pre-screen")
+    eng24.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100, seed=seed, mpopt=so)
+    t1 = time.perf_counter()
+    r = eng24.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100, seed=seed, mpopt=so)
+    res["time_to_cov_1pct"] = {"seconds": time.perf_counter() - t1, "samples": r.current_iteration, "beta": r.current_beta, "batch": 100, "n_screened_frac": r.n_screened / max(1, r.current_iteration)}
+    eng24.db_reset(); eng24.nsq_db_batch(seed, 0, B, so); eng24.db_reset()
+    t1 = time.perf_counter(); _, st = eng24.nsq_db_batch(seed, 0, B, so); dtb = time.perf_counter() - t1
+    eng24.db_reset()
+    t1 = time.perf_counter()
+    r2 = eng24.nsqMain(beta_limit=0.0017, max_iterations=50_000_000, samples_per_batch=1_000_000, seed=seed, mpopt=so, distinct_states="database")
+    res["distinct_state_path"] = {"first_batch_from_empty_ms": dtb * 1e3, "first_batch_rows": int(st.rows),
+                                  "time_to_reference_beta_limit_0.0017": {"seconds": time.perf_counter() - t1, "samples": r2.current_iteration, "beta": r2.current_beta,
+                                                                          "rows": r2.database_row_count, "n_screened_frac": r2.n_screened / max(1, r2.current_iteration)}}
+    eng24.db_reset()
+    sq = rseq.SeqEngine(eng24)
+    Y = 125
+    outs, dt, kms = timed(lambda k: sq.seq_years(seed, (1 << 20) + k * Y, Y, so)[4], eng24)
+    lp = sum(int(a.n) for a in outs) / len(outs)
+    res["seq"] = line(outs, dt, kms, lp, "hourly DC-OPFs/s", f"HL2 sequential MCS, RTS-24, {Y} simulated years x 8736 h per step, contingency hours only, behind the pre-screen")
+    res["seq"]["years_per_s"] = Y / dt
+    e96 = api.Engine(case96.rts96(), device=device)
+    accs, dt, kms = timed(lambda k: e96.nsq_accumulate(seed, (1 << 41) + k * B, B, so), e96)
+    res["rts96"] = line(accs, dt, kms, B, "scenarios/s", f"HL2 non-sequential MCS, IEEE RTS-96, {B} samples per step behind the pre-screen")
+    e96.close()
     return res
 
 
