@@ -10,7 +10,7 @@ import csv, glob, collections
 for p in ('p1','p2','p3'):
     f = glob.glob('$OUT/'+p+'/*counter_collection.csv')
     if not f: print(p, 'no csv'); continue
-    rows = [r for r in csv.DictReader(open(f[0])) if 'eval_kernel' in r['Kernel_Name']]
+    rows = [r for r in csv.DictReader(open(f[0])) if 'eval_kernel<0' in r['Kernel_Name']]
     last = max(int(r['Dispatch_Id']) for r in rows)
     print(p, {r['Counter_Name']: float(r['Counter_Value']) for r in rows if int(r['Dispatch_Id'])==last})
 PY

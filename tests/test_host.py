@@ -368,7 +368,7 @@ def test_plain_bench_command_runs_two_ranks(tmp_path):
     import torch
     if torch.cuda.device_count() < 3:
         bad = _plain_bench(tmp_path, "p3", ["--gpus", "3", "--steps", "1", "--warmup", "0"], expect_ok=False)
-        assert bad.returncode == 6 and "--gpus 3 but this node has" in bad.stderr and '"metric"' not in bad.stdout
+        assert bad.returncode == 6 and "3 ranks on this node (--gpus 3) but it has 1 GPU" in bad.stderr and '"metric"' not in bad.stdout
 
 
 @pytest.mark.gpu
