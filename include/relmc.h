@@ -268,9 +268,16 @@ int32_t relmc_comm_destroy(relmc_ctx* ctx);
  * the global sample stream is split contiguously over the ranks, one all-reduce per batch, every rank returns the same result
  * (nsqMain.m:208-318 around the parfor of :257-263); relmc_comm_allreduce_acc goes through the registered collective as well.
  * relmc_comm_info: kind 0 = none, 1 = RCCL (ranks / rank as ncclCommCount / ncclCommUserRank report them), 2 = host collective;
- * all-reduces of relmc_acc issued through this context and the wall time spent in them.  Any output may be NULL. */
+ * all-reduces issued through this context (of relmc_acc, and of vectors: relmc_comm_allreduce_f64 counts once per call) and the wall time
+ * spent in them.  Any output may be NULL. */
 typedef int32_t (*relmc_allreduce_fn)(void* user, relmc_acc* acc_inout);
 int32_t relmc_comm_set_host_allreduce(relmc_ctx* ctx, int32_t nranks, int32_t rank, relmc_allreduce_fn fn, void* user);
+/* Optional vector transport of a host collective (after relmc_comm_set_host_allreduce): fn(user, buf, count) leaves the sum over all ranks of
+ * `count` doubles in buf on every rank (0 = ok).  relmc_comm_allreduce_f64 -- the all-gather of the sequential loop's annual indices
+ * (seqMain.m:112-133) and the per-checkpoint sums of relmc_nsq_run's stretches -- is then ONE callback per call instead of count / 130 through the
+ * relmc_acc callback.  NULL removes it. */
+typedef int32_t (*relmc_allreduce_f64_fn)(void* user, double* buf_inout, int64_t count);
+int32_t relmc_comm_set_host_allreduce_f64(relmc_ctx* ctx, relmc_allreduce_f64_fn fn, void* user);
 int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks_out, int32_t* rank_out, int64_t* calls_out,
                         double* seconds_out);
 /* Wall-clock guard.  relmc_comm_init and every collective issued through the context (RCCL or the host's callback) must finish within
@@ -279,8 +286,8 @@ int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks
  * exit code 86 -- a multi-GPU job that would hang for the launcher's own timeout becomes a diagnosis within two minutes. */
 int32_t relmc_comm_set_timeout(relmc_ctx* ctx, double seconds);
 /* Sum over the ranks of `count` doubles, in place (same result on every rank).  The sequential loop all-gathers its annual indices with it
- * (every rank fills its own slots of a zeroed vector: x + 0 + ... + 0 is exact).  RCCL: one ncclAllReduce; a host collective: the
- * registered relmc_acc all-reduce, 130 doubles per call. */
+ * (every rank fills its own slots of a zeroed vector: x + 0 + ... + 0 is exact).  RCCL: one ncclAllReduce; a host collective: one call of
+ * the vector transport (relmc_comm_set_host_allreduce_f64) if there is one, else the registered relmc_acc all-reduce, 130 doubles per call. */
 int32_t relmc_comm_allreduce_f64(relmc_ctx* ctx, double* buf_inout, int64_t count);
 /* PCI bus id of the GPU the context drives ("0000:c1:00.0", cap >= 16): what a multi-rank host gathers to show its ranks sit on DISTINCT devices */
 int32_t relmc_device_pci_bus_id(const relmc_ctx* ctx, char* out, int32_t cap);

@@ -274,6 +274,11 @@ accumulators it is handed (0 = ok), e.g. MPI.Allreduce! on the two halves of the
 comm_set_host_allreduce(eng::Engine, nranks::Integer, rank::Integer, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL) =
     check(ccall((:relmc_comm_set_host_allreduce, LIB), Int32, (Ptr{Cvoid}, Int32, Int32, Ptr{Cvoid}, Ptr{Cvoid}), eng.h, nranks, rank, fn, user),
           eng.h, "relmc_comm_set_host_allreduce")
+"Vector transport of the host collective: `fn = @cfunction(f, Int32, (Ptr{Cvoid}, Ptr{Cdouble}, Int64))` leaves the sum over all ranks of `count` doubles
+in the buffer (e.g. MPI.Allreduce!); the library's vector all-reduces (annual indices, per-checkpoint sums) are then one callback each
+(relmc_comm_set_host_allreduce_f64)."
+comm_set_host_allreduce_f64(eng::Engine, fn::Ptr{Cvoid}, user::Ptr{Cvoid}=C_NULL) =
+    check(ccall((:relmc_comm_set_host_allreduce_f64, LIB), Int32, (Ptr{Cvoid}, Ptr{Cvoid}, Ptr{Cvoid}), eng.h, fn, user), eng.h, "relmc_comm_set_host_allreduce_f64")
 "(kind 0 none / 1 RCCL / 2 host, ranks, this rank, all-reduces issued, seconds in them) as the communicator itself reports (relmc_comm_info)"
 function comm_info(eng::Engine)
     kind = Ref{Int32}(0); n = Ref{Int32}(0); r = Ref{Int32}(0); calls = Ref{Int64}(0); sec = Ref{Cdouble}(0.0)

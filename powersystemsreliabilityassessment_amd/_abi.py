@@ -80,6 +80,8 @@ class Acc(C.Structure):
 
 # relmc_allreduce_fn: int32 fn(void* user, relmc_acc* acc_inout)
 ALLREDUCE_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, C.POINTER(Acc))
+# relmc_allreduce_f64_fn: int32 fn(void* user, double* buf_inout, int64 count)
+ALLREDUCE_F64_FN = C.CFUNCTYPE(C.c_int32, C.c_void_p, c_double_p, C.c_int64)
 
 
 class Indices(C.Structure):

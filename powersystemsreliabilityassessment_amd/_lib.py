@@ -27,7 +27,7 @@ EXPORTS = [
     "relmc_db_reset", "relmc_nsq_db_batch", "relmc_db_accumulate", "relmc_db_size", "relmc_db_export", "relmc_db_import",
     "relmc_seq_load", "relmc_seq_mcsampling", "relmc_seq_mcsimulation", "relmc_seq_years", "relmc_retry_stats", "relmc_retry_overflow", "relmc_retry_dense_stats", "relmc_case_order",
     "relmc_case_order_hint", "relmc_tune_order",
-    "relmc_comm_set_timeout", "relmc_comm_allreduce_f64", "relmc_device_pci_bus_id", "relmc_seq_opts_default", "relmc_seq_run",
+    "relmc_comm_set_timeout", "relmc_comm_allreduce_f64", "relmc_comm_set_host_allreduce_f64", "relmc_device_pci_bus_id", "relmc_seq_opts_default", "relmc_seq_run",
 ]
 
 
@@ -143,6 +143,8 @@ def load():
     L.relmc_comm_set_host_allreduce.restype = C.c_int32
     L.relmc_comm_info.argtypes = [vp, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int32_p, _abi.c_int64_p, _abi.c_double_p]
     L.relmc_comm_info.restype = C.c_int32
+    L.relmc_comm_set_host_allreduce_f64.argtypes = [vp, _abi.ALLREDUCE_F64_FN, vp]
+    L.relmc_comm_set_host_allreduce_f64.restype = C.c_int32
     L.relmc_comm_set_timeout.argtypes = [vp, C.c_double]
     L.relmc_comm_set_timeout.restype = C.c_int32
     L.relmc_comm_allreduce_f64.argtypes = [vp, dp, C.c_int64]

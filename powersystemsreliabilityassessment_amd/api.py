@@ -62,7 +62,6 @@ class NsqResult:
     n_singular: int
     n_infeasible: int
     n_nonconverged: int
-    n_screened: int                 # samples the zero-curtailment pre-screen counted without solving (mpoption(screen=1); 0 otherwise)
     elapsed_time: float
     kernel_seconds: float
     acc: _abi.Acc = field(repr=False, default=None)
@@ -70,6 +69,7 @@ class NsqResult:
     beta_limit: float = 0.0017
     database_row_count: int | None = None      # unique states evaluated (only the database path keeps them)
     hours_per_year: float = 8760.0
+    n_screened: int = 0             # samples the zero-curtailment pre-screen counted without solving (mpoption(screen=1); 0 otherwise)
 
     # -- what nsqMain prints (nsqMain.m:314-317, 325-393) ---------------------------------------------------------
     def progress_lines(self, every: int = 1000) -> list[str]:

@@ -152,7 +152,12 @@ int comm_allreduce_f64(relmc_ctx* ctx, double* buf, int64_t count)
 {
     if (count <= 0 || comm_ranks(ctx) <= 1) return RELMC_OK;
     const auto t0 = std::chrono::steady_clock::now();
-    struct Tick { relmc_ctx* c; std::chrono::steady_clock::time_point t; ~Tick() { c->comm_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } tick{ctx, t0};
+    struct Tick { relmc_ctx* c; std::chrono::steady_clock::time_point t; ~Tick() { c->comm_calls++; c->comm_seconds += std::chrono::duration<double>(std::chrono::steady_clock::now() - t).count(); } } tick{ctx, t0};
+    if (ctx->host_allreduce && ctx->host_allreduce_f64) {      // the host's vector transport: one callback
+        Guard g(ctx, "the host's vector all-reduce callback", ctx->comm_nranks, ctx->comm_rank);
+        const int32_t rc = ctx->host_allreduce_f64(ctx->host_allreduce_f64_user, buf, count);
+        return rc == 0 ? RELMC_OK : fail(ctx, RELMC_ERR_HIP, "comm_allreduce_f64: the host's vector all-reduce returned " + std::to_string(rc));
+    }
     if (ctx->host_allreduce) {
         // through the host's relmc_acc all-reduce, 130 doubles per call (sum_dns, sum_dns2, sum_nodal): the integers ride along as zeros
         constexpr int64_t kPer = 2 + RELMC_MAX_BUS;
@@ -243,6 +248,14 @@ int32_t relmc_comm_set_host_allreduce(relmc_ctx* ctx, int32_t nranks, int32_t ra
     return RELMC_OK;
 }
 
+int32_t relmc_comm_set_host_allreduce_f64(relmc_ctx* ctx, relmc_allreduce_f64_fn fn, void* user)
+{
+    if (!ctx) return RELMC_ERR_INVALID;
+    if (!ctx->host_allreduce) return fail(ctx, RELMC_ERR_INVALID, "relmc_comm_set_host_allreduce_f64: register the relmc_acc collective first (relmc_comm_set_host_allreduce)");
+    ctx->host_allreduce_f64 = fn; ctx->host_allreduce_f64_user = user;
+    return RELMC_OK;
+}
+
 // what the communicator itself says: kind 0 none, 1 RCCL (ranks and rank from ncclCommCount / ncclCommUserRank), 2 host collective
 int32_t relmc_comm_info(const relmc_ctx* ctx, int32_t* kind_out, int32_t* nranks_out, int32_t* rank_out, int64_t* calls_out, double* seconds_out)
 {
@@ -302,6 +315,7 @@ int32_t relmc_comm_destroy(relmc_ctx* ctx)
     if (!ctx) return RELMC_ERR_INVALID;
     if (ctx->comm && g_rccl.CommDestroy) { (void)hipSetDevice(ctx->device); (void)g_rccl.CommDestroy(ctx->comm); }
     ctx->comm = nullptr; ctx->comm_nranks = 0; ctx->comm_rank = -1; ctx->host_allreduce = nullptr; ctx->host_allreduce_user = nullptr;
+    ctx->host_allreduce_f64 = nullptr; ctx->host_allreduce_f64_user = nullptr;
     return RELMC_OK;
 }
 

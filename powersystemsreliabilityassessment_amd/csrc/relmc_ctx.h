@@ -102,6 +102,7 @@ struct relmc_ctx {
     // communicator over the ranks of a multi-GPU run (optional; relmc_comm_*): RCCL, or the host's own collective
     void* comm = nullptr; int comm_nranks = 0, comm_rank = -1;
     relmc_allreduce_fn host_allreduce = nullptr; void* host_allreduce_user = nullptr;
+    relmc_allreduce_f64_fn host_allreduce_f64 = nullptr; void* host_allreduce_f64_user = nullptr;   // optional vector transport of the host collective
     int64_t comm_calls = 0; double comm_seconds = 0.0;                                     // all-reduces of relmc_acc through this context, wall time in them
     double comm_timeout_s = 120.0;                                                         // wall-clock guard of communicator init and of every collective
     void* watchdog = nullptr;                                                              // the guard's thread (relmc_comm.hip), started at the first guarded call

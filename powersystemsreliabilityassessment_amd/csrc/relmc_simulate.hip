@@ -292,7 +292,123 @@ int32_t relmc_nsq_run(relmc_ctx* ctx, const relmc_nsq_opts* o, relmc_nsq_result*
     // do not depend on the number of ranks, the fp64 sums only in their summation order.  The state database (distinct_states = 2) is per
     // rank (each rank's rows are the states of ITS slices); its accumulators are cumulative, so they are all-reduced as they are.
     const int nranks = comm_ranks(ctx);
-    if (nranks > 1) {
+    // ... with small batches (the reference's own is 100, nsqMain.m:60) in STRETCHES like the single-rank loop below: every rank evaluates its
+    // contiguous slice of a stretch of whole batches with the dns of each of its samples, folds it into per-checkpoint (sum dns, sum dns^2, losses)
+    // partial triples, ONE all-reduce of 3 x checkpoints + the accumulators (as doubles: the counts are exact below 2^53) per stretch gives every rank
+    // every checkpoint of the stretch; all ranks walk the same checkpoints and cut at the same one; a cut stretch is taken again over its used part
+    // (one more all-reduce), so the run stops at the batch-by-batch loop's checkpoint with its accumulators.  Stretch lengths follow the
+    // single-rank rule, so the checkpoints at which the history restarts from the accumulators are the single-rank run's.
+    if (nranks > 1 && o->distinct_states == 0 && o->batch <= kStretchMaxBatch && !ctx->sw.nsq_no_stretch) {
+        const int64_t R = nranks, r = ctx->comm_rank;
+        const int64_t per = kStretch / o->batch * o->batch;
+        HIP_TRY(ctx, hipSetDevice(ctx->device));
+        if (ctx->hist_cap < per) {
+            if (ctx->dhist) (void)hipFree(ctx->dhist);
+            if (ctx->hhist) (void)hipHostFree(ctx->hhist);
+            ctx->dhist = ctx->hhist = nullptr; ctx->hist_cap = 0;
+            HIP_TRY(ctx, hipMalloc(&ctx->dhist, sizeof(double) * (size_t)per));
+            HIP_TRY(ctx, hipHostMalloc(&ctx->hhist, sizeof(double) * (size_t)per, hipHostMallocDefault));
+            ctx->hist_cap = per;
+        }
+        constexpr int64_t NI = (int64_t)(offsetof(relmc_acc, sum_dns) / sizeof(int64_t)), ND = (int64_t)((sizeof(relmc_acc) - offsetof(relmc_acc, sum_dns)) / sizeof(double));
+        std::vector<double> box;
+        auto pack = [&](const relmc_acc& a, double* q) {
+            const int64_t* ai = reinterpret_cast<const int64_t*>(&a); const double* ad = &a.sum_dns;
+            for (int64_t k = 0; k < NI; ++k) q[k] = (double)ai[k];
+            for (int64_t k = 0; k < ND; ++k) q[NI + k] = ad[k];
+        };
+        auto unpack = [&](const double* q, relmc_acc& a) {
+            int64_t* ai = reinterpret_cast<int64_t*>(&a); double* ad = &a.sum_dns;
+            for (int64_t k = 0; k < NI; ++k) ai[k] = (int64_t)std::llround(q[k]);
+            for (int64_t k = 0; k < ND; ++k) ad[k] = q[NI + k];
+        };
+        // this rank's slice of [lo0, lo0 + len): accumulators (and, with trip, the per-checkpoint partial triples), all-reduced over the ranks
+        auto shared_eval = [&](int64_t lo0, int64_t len, double* trip, int64_t ncp, relmc_acc* out) -> int {
+            const int64_t lo = lo0 + len * r / R, cnt = lo0 + len * (r + 1) / R - lo;
+            relmc_acc part;
+            relmc_acc_zero(&part);
+            int rc = RELMC_OK;
+            if (cnt > 0) {
+                rc = nsq_accumulate_impl(ctx, o->seed, (uint64_t)lo, cnt, &o->solver, &part, trip ? ctx->dhist : nullptr);
+                if (rc == RELMC_OK) kernel_ms += ctx->last_kernel_ms;
+                if (rc == RELMC_OK && trip) {
+                    if (hipMemcpyAsync(ctx->hhist, ctx->dhist, sizeof(double) * (size_t)cnt, hipMemcpyDeviceToHost, ctx->stream) != hipSuccess ||
+                        hipStreamSynchronize(ctx->stream) != hipSuccess) rc = fail(ctx, RELMC_ERR_HIP, "relmc_nsq_run: copy of the per-sample dns failed");
+                }
+            }
+            const std::string local_err = ctx->err;
+            box.assign((size_t)(3 * ncp + NI + ND), 0.0);
+            if (rc == RELMC_OK) {
+                if (trip) for (int64_t i = 0; i < cnt; ++i) {
+                    const double v = ctx->hhist[(size_t)i];
+                    double* t = &box[(size_t)(3 * ((lo - lo0 + i) / o->batch))];
+                    t[0] += v; t[1] = std::fma(v, v, t[1]); t[2] += v > 1e-4 /* nsqMain.m:270 */ ? 1.0 : 0.0;
+                }
+                pack(part, &box[(size_t)(3 * ncp)]);
+            } else box[(size_t)(3 * ncp)] = NAN;             // a rank whose slice failed still enters the collective and says so where every rank looks
+            const int rc_ar = comm_allreduce_f64(ctx, box.data(), (int64_t)box.size());
+            if (rc != RELMC_OK) { ctx->err = local_err; return rc; }
+            if (rc_ar) return rc_ar;
+            if (box[(size_t)(3 * ncp)] != box[(size_t)(3 * ncp)]) return fail(ctx, RELMC_ERR_HIP, "relmc_nsq_run: another rank failed to evaluate its slice of the stretch (see that rank's relmc_last_error)");
+            if (trip) std::memcpy(trip, box.data(), sizeof(double) * (size_t)(3 * ncp));
+            unpack(&box[(size_t)(3 * ncp)], *out);
+            return RELMC_OK;
+        };
+        std::vector<double> trip;
+        while (beta > o->beta_limit && done < o->max_samples) {
+            // stretch length: the single-rank rule (below), on the same (done, beta): ~25 600 samples, then as many as the run holds, then from beta
+            const int64_t first = 25600 / o->batch > 0 ? 25600 / o->batch * o->batch : o->batch;
+            const int64_t least = 1600 / o->batch > 0 ? 1600 / o->batch * o->batch : o->batch;
+            int64_t len = done > first ? done / o->batch * o->batch : first;
+            bool final_stretch = false;
+            if (done > 0 && o->beta_limit > 0.0 && beta < 1e6 && beta > o->beta_limit) {
+                const double need = (double)done * (beta / o->beta_limit) * (beta / o->beta_limit);
+                const double target = (double)done < 0.85 * need ? 0.9 * need : 1.03 * need;
+                const double l = std::ceil((target - (double)done) / (double)o->batch) * (double)o->batch;
+                len = l < (double)least ? least : (l > (double)per ? per : (int64_t)l);
+                final_stretch = !((double)done < 0.85 * need);
+            }
+            if (len > per) len = per;
+            if (!final_stretch) {
+                const int64_t round = (int64_t)ctx->num_cu * ctx->blocks_per_cu * (ctx->tile == 0 ? Tile24::WPB * Tile24::SPW : Tile96::WPB * Tile96::SPW);
+                const int64_t snapped = (len / round) * round / o->batch * o->batch;
+                if (len >= 2 * round && snapped >= least) len = snapped;
+            }
+            const int64_t m = (o->max_samples - done) < len ? (o->max_samples - done) : len;
+            const int64_t ncp = (m + o->batch - 1) / o->batch;
+            trip.assign((size_t)(3 * ncp), 0.0);
+            relmc_acc part;
+            const int64_t ru0 = ctx->retry_units, rc0_ = ctx->retry_converged, rd0 = ctx->retry_dense_units, rdc0 = ctx->retry_dense_converged, ro0 = ctx->retry_overflow;
+            const double kernel_ms0 = kernel_ms;
+            int rc = shared_eval(done, m, trip.data(), ncp, &part);
+            if (rc) return rc;
+            relmc_acc run = res->acc;
+            int64_t used = 0;
+            for (int64_t k = 0; k < ncp; ++k) {
+                const int64_t b = (m - used) < o->batch ? (m - used) : o->batch;
+                run.n += b; run.n_fail += (int64_t)std::llround(trip[(size_t)(3 * k + 2)]); run.sum_dns += trip[(size_t)(3 * k)]; run.sum_dns2 += trip[(size_t)(3 * k + 1)];
+                used += b;
+                relmc_indices ix;
+                relmc_nsq_indices(&run, 0, 0, o->hours_per_year, &ix);
+                beta = ix.beta;
+                checkpoint(ix);
+                if (beta <= o->beta_limit) break;
+            }
+            if (used < m) {                                    // cut: the stretch again over its used part, on every rank (they all see the same beta)
+                ctx->retry_units = ru0; ctx->retry_converged = rc0_; ctx->retry_dense_units = rd0; ctx->retry_dense_converged = rdc0; ctx->retry_overflow = ro0;
+                kernel_ms = kernel_ms0;
+                rc = shared_eval(done, used, nullptr, 0, &part);
+                if (rc) return rc;
+            }
+            relmc_acc_merge(&res->acc, &part);
+            done += used;
+            relmc_nsq_indices(&res->acc, nb, ncomp, o->hours_per_year, &res->idx);
+            beta = res->idx.beta;
+            cp--;
+            checkpoint(res->idx);
+        }
+    }
+    else if (nranks > 1) {
         const int64_t R = nranks, r = ctx->comm_rank;
         while (beta > o->beta_limit && done < o->max_samples) {
             const int64_t m = (o->max_samples - done) < o->batch ? (o->max_samples - done) : o->batch;

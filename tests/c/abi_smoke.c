@@ -46,7 +46,23 @@ static int run_two_ranks(const relmc_case_desc* d, const int32_t* order, const r
 
 /* ---- relmc_seq_run (seqMain.m:85-249 below the ABI): alone, with the one-rank RCCL communicator, and as TWO ranks of this process --
  * two threads, two contexts, and a host collective that is a two-party rendezvous (what an MPI / Julia Distributed host would register). */
-typedef struct { pthread_mutex_t m; pthread_cond_t cv; relmc_acc sum, result[2]; int arrived; unsigned generation; int calls; } pair_t;
+enum { PAIR_VEC = 1 << 15 };
+typedef struct { pthread_mutex_t m; pthread_cond_t cv; relmc_acc sum, result[2]; int arrived; unsigned generation; int calls;
+                 double vsum[PAIR_VEC], vres[2][PAIR_VEC]; int varrived; unsigned vgeneration; int vcalls; } pair_t;
+/* the vector transport of the same rendezvous (relmc_comm_set_host_allreduce_f64): ONE callback per all-gather of the annual indices */
+static int32_t pair_allreduce_f64(void* user, double* buf, int64_t count)
+{
+    pair_t* p = (pair_t*)user;
+    if (count > PAIR_VEC) return 1;
+    pthread_mutex_lock(&p->m);
+    const unsigned gen = p->vgeneration;
+    if (p->varrived == 0) memcpy(p->vsum, buf, sizeof(double) * (size_t)count); else for (int64_t k = 0; k < count; ++k) p->vsum[k] += buf[k];
+    if (++p->varrived == 2) { memcpy(p->vres[gen & 1u], p->vsum, sizeof(double) * (size_t)count); p->varrived = 0; p->vgeneration++; p->vcalls++; pthread_cond_broadcast(&p->cv); }
+    else while (gen == p->vgeneration) pthread_cond_wait(&p->cv, &p->m);
+    memcpy(buf, p->vres[gen & 1u], sizeof(double) * (size_t)count);
+    pthread_mutex_unlock(&p->m);
+    return 0;
+}
 static int32_t pair_allreduce(void* user, relmc_acc* acc)
 {
     pair_t* p = (pair_t*)user;
@@ -103,9 +119,11 @@ static int run_seq(relmc_ctx* ctx, const relmc_case_desc* d, const int32_t* orde
     relmc_ctx* c1 = NULL;
     if (relmc_ctx_create(0, &c1) != RELMC_OK || relmc_case_order_hint(c1, order, d->nb) != RELMC_OK || relmc_case_load(c1, d) != RELMC_OK ||
         relmc_seq_load(c1, mttf, mttr, hpy, lf) != RELMC_OK) return 8;
-    pair_t pair; memset(&pair, 0, sizeof(pair));
+    static pair_t pair; memset(&pair, 0, sizeof(pair));
     pthread_mutex_init(&pair.m, NULL); pthread_cond_init(&pair.cv, NULL);
+    if (relmc_comm_set_host_allreduce_f64(ctx, pair_allreduce_f64, &pair) == RELMC_OK) return 9;                /* refused before the relmc_acc collective is there */
     if (relmc_comm_set_host_allreduce(ctx, 2, 0, pair_allreduce, &pair) != RELMC_OK || relmc_comm_set_host_allreduce(c1, 2, 1, pair_allreduce, &pair) != RELMC_OK) return 9;
+    if (relmc_comm_set_host_allreduce_f64(ctx, pair_allreduce_f64, &pair) != RELMC_OK || relmc_comm_set_host_allreduce_f64(c1, pair_allreduce_f64, &pair) != RELMC_OK) return 9;
     o.batch_years = 0;
     seq_rank_t t0 = {ctx, &o, plain, y_r0, -1}, t1 = {c1, &o, plain, y_r1, -1};
     pthread_t th;
@@ -114,6 +132,8 @@ static int run_seq(relmc_ctx* ctx, const relmc_case_desc* d, const int32_t* orde
     pthread_join(th, NULL);
     if (t0.rc != RELMC_OK || t1.rc != RELMC_OK) { fprintf(stderr, "seq two ranks: %s | %s\n", relmc_last_error(ctx), relmc_last_error(c1)); return 11; }
     if (!same_seq(&t0.r, &t1.r, y_r0, y_r1, 1) || !same_seq(&plain, &t0.r, y_plain, y_r0, 0) || pair.calls < 2) return 12;
+    /* the annual indices went through the vector transport: one callback per batch of years, none through the 130-double path */
+    if (pair.vcalls < 1 || pair.vcalls > pair.calls) return 13;
     relmc_comm_destroy(ctx); relmc_ctx_destroy(c1);
     pthread_mutex_destroy(&pair.m); pthread_cond_destroy(&pair.cv);
     return 0;
