@@ -190,7 +190,7 @@ int main(int argc, char** argv)
     /* relmc_nsq_run with that communicator in the context: the no-communicator result bit for bit (one rank = nothing to split);
      * the communicator reports its own size */
     relmc_nsq_opts no; relmc_nsq_opts_default(&no);
-    no.beta_limit = 0.02; no.max_samples = 200000; no.batch = 20000; no.seed = 4;
+    no.beta_limit = 0.02; no.max_samples = 200000; no.batch = 40000; no.seed = 4;      /* above 32 768: one launch and one all-reduce per batch (smaller batches run in stretches) */
     relmc_nsq_result r_comm, r_plain;
     int32_t kind = -1, nr = -1, rk = -1; int64_t calls = -1; double secs = -1.0;
     if (relmc_nsq_run(ctx, &no, &r_comm) != RELMC_OK) { fprintf(stderr, "%s\n", relmc_last_error(ctx)); return 16; }
