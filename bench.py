@@ -45,6 +45,7 @@ def dense_flop_per_iter(nb):
 
 EXIT_WORLD_MISMATCH = 7         # WORLD_SIZE of the launcher != --gpus
 EXIT_TOO_FEW_GPUS = 6           # --gpus exceeds the GPUs of the node (and --share-device was not asked for)
+EXIT_RANKS_DIVERGED = 8         # a rank finished cleanly while its peers were still running long after: they wait for it in a collective it never entered
 
 
 def _free_port():
@@ -64,13 +65,15 @@ def _die_with_parent():
         pass
 
 
-def launch_ranks(n, argv, poll=0.05, grace=5.0, script=None):
+def launch_ranks(n, argv, poll=0.05, grace=5.0, script=None, straggler_s=120.0):
     """`bench.py --gpus N` called plainly: the analogue of opening the reference's parfor pool (nsqMain.m:257-263, seqMain.m:112-133).
     The parent has imported neither torch nor the package and holds no GPU state; it starts N FRESH processes of this very script with the
     same arguments plus RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR=127.0.0.1 / a free MASTER_PORT (never a re-exec of itself), lets rank 0
     write the JSON line to the parent's stdout (the other ranks' stdout goes to stderr), and waits.  The first rank that leaves with a
     non-zero code (86 = a guarded collective stalled, 3 = communicator refused, 4 = rank-count mismatch, 5 = duplicate GPUs, 6 = too few
-    GPUs) ends the run: the remaining ranks are terminated by pid and the parent exits with that code."""
+    GPUs) ends the run: the remaining ranks are terminated by pid and the parent exits with that code.  A rank that leaves with code 0 while
+    others are still running `straggler_s` seconds later (every rank ends after the same last collective) is a divergence, not a success: the
+    rest is stopped and the parent exits with code 8."""
     import signal
     import subprocess
     port = _free_port()
@@ -101,6 +104,7 @@ def launch_ranks(n, argv, poll=0.05, grace=5.0, script=None):
     signal.signal(signal.SIGTERM, on_signal)
     signal.signal(signal.SIGINT, on_signal)
     code = 0
+    first_clean_exit = None
     while True:
         running = 0
         for r, p in enumerate(procs):
@@ -110,6 +114,12 @@ def launch_ranks(n, argv, poll=0.05, grace=5.0, script=None):
             elif rc != 0 and code == 0:
                 code = rc if rc > 0 else 128 - rc
                 print(f"bench.py: rank {r} of {n} (pid {p.pid}) left with code {rc}: stopping the other ranks", file=sys.stderr, flush=True)
+            elif rc == 0 and first_clean_exit is None:
+                first_clean_exit = (time.time(), r)
+        if not code and running and first_clean_exit is not None and time.time() - first_clean_exit[0] > straggler_s:
+            code = EXIT_RANKS_DIVERGED
+            print(f"bench.py: rank {first_clean_exit[1]} of {n} finished {straggler_s:.0f} s ago and {running} rank(s) are still running: the ranks took "
+                  f"different paths (a collective one of them never entered); stopping them", file=sys.stderr, flush=True)
         if code or not running:
             break
         time.sleep(poll)
@@ -470,7 +480,7 @@ def main():
             out["distinct_state_path"] = db_multi
         out["launcher"] = "bench.py --gpus N (self-started ranks)" if os.environ.get("RELMC_BENCH_LAUNCHER") == "bench.py" else ("external (RANK / WORLD_SIZE from the environment)" if world > 1 else "none (single rank)")
         if world > 1:
-            out["omitted"] = {"keys": ["cpu_baseline", "secondary", "screened", "sustained"] + (["time_to_cov_1pct", "distinct_state_path"] if args.workload != "nsq24" or args.no_time_to_cov else []),
+            out["omitted"] = {"keys": None,
                               "why": "N > 1 lines are scaling rows: the CPU baseline, the other BASELINE configurations and the sustained-rate leg are measured on rank 0 at N = 1 only"}
         if world == 1 and args.workload == "nsq24" and not args.no_time_to_cov:
             # the reference checks beta every 100 samples (nsqMain.m:60, 299-312): the same spacing here (relmc_nsq_run evaluates stretches of
@@ -512,6 +522,8 @@ def main():
             out["screened"] = screened_rates(eng, local_rank, policy, args.seed, B)
         if world == 1 and not args.no_cpu_baseline and args.workload == "nsq24":
             out["cpu_baseline"] = cpu_baseline(case, policy, args.seed, args.cpu_sample)
+        if "omitted" in out:          # what a full N = 1 line carries and this one does not, from what was actually emitted
+            out["omitted"]["keys"] = [k for k in ("cpu_baseline", "secondary", "screened", "sustained", "time_to_cov_1pct", "distinct_state_path") if k not in out]
         if args.dump_acc:
             ints, dbls = total.to_arrays()
             with open(args.dump_acc, "w") as fh:

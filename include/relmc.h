@@ -366,7 +366,7 @@ typedef struct {
     int32_t final_year;       /* years simulated = the stopping year (seqMain.m:203) */
     int32_t converged;        /* CoV < cov_threshold reached (:194) */
     double eens;              /* MWh/yr, results_cum.eens(end)     */
-    double cov;               /* results_cum.cov(end)              */
+    double cov;               /* results_cum.cov(end); NaN (0 / 0, as seqMain.m:184) if no simulated year had curtailment */
     double lole;              /* h/yr, mean(results_year.dlc), :212 */
     double lolf;              /* occ/yr, mean(results_year.nlc), :213 */
     double plc;               /* mean(results_year.plc)            */

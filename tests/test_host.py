@@ -461,13 +461,19 @@ def test_bench_comm_paths_are_self_evidencing(tmp_path):
         assert out.returncode == 0, out.stderr[-2000:]
         line = [ln for ln in out.stdout.splitlines() if ln.startswith("{") and '"metric"' in ln][-1]
         return json.loads(line), json.load(open(f))
-    j1, a1 = run(1, ["--batch", "100000", "--no-time-to-cov"], "n1")
+    j1, a1 = run(1, ["--batch", "100000", "--no-time-to-cov", "--no-sustained"], "n1")
     assert j1["comm"]["backend"] == "none" and j1["comm"]["nranks_seen"] == 1 and j1["comm"]["allreduce_bytes"] == C.sizeof(_abi.Acc)
     assert len(j1["comm"]["devices"]) == 1 and re.fullmatch(r"[0-9a-fA-F]{4}:[0-9a-fA-F]{2}:[0-9a-fA-F]{2}\.[0-9a-fA-F]", j1["comm"]["devices"][0]), j1["comm"]["devices"]
     # the other BASELINE configs ride along outside the timed region: RTS-96, sequential, HL1 copper sheet
     sec = j1["secondary"]
     assert set(sec) == {"rts96", "seq", "hl1"} and all(sec[k]["value"] > 0 and sec[k]["ms_per_step"] > 0 and sec[k]["kernel_ms_avg"] > 0 for k in sec)
     assert sec["rts96"]["n_nonconverged"] == 0 and 12.0 < sec["rts96"]["mean_ipm_iterations"] < 13.5 and 0.05 < sec["rts96"]["frac_executed"] < 0.3
+    # ... and the same workloads behind the zero-curtailment pre-screen (relmc_solver_opts.screen), beside the headline, never as `value`
+    scr = j1["screened"]
+    assert {"nsq24", "rts96", "seq", "time_to_cov_1pct", "distinct_state_path"} <= set(scr)
+    assert 0.88 < scr["nsq24"]["n_screened_frac"] < 0.93 and 0.95 < scr["rts96"]["n_screened_frac"] < 0.99 and scr["seq"]["n_screened_frac"] > 0.98
+    assert scr["nsq24"]["value"] > 2.0 * j1["value"] and scr["rts96"]["value"] > 2.0 * sec["rts96"]["value"] and scr["seq"]["value"] > 2.0 * sec["seq"]["value"]
+    assert scr["time_to_cov_1pct"]["samples"] == 211_200 and all(scr[k]["n_nonconverged"] == 0 for k in ("nsq24", "rts96", "seq"))
     assert sec["seq"]["n_nonconverged"] == 0 and sec["seq"]["years_per_s"] > 100 and sec["hl1"]["lole_h_per_yr"] == pytest.approx(9.39, rel=0.05)
     assert len(j1["kernel_ms_per_rank"]) == 1 and j1["kernel_ms_per_rank"][0] > 0
     j2, a2 = run(2, ["--batch", "50000", "--comm", "host"], "h2")
@@ -570,8 +576,9 @@ def test_bench_says_when_the_quoted_counters_are_not_about_this_binary(tmp_path)
     blob[at + 64] ^= 1
     other.write_bytes(bytes(blob))
     assert _lib.code_object_sha256(str(other)) != h
+    from oracle import coracle
     with pytest.raises(_lib.RelmcLibraryError):
-        _lib.code_object_sha256(os.path.join(ROOT, "oracle", "librelmc_oracle.so"))       # a CPU library carries no device code
+        _lib.code_object_sha256(coracle.build())                                          # a CPU library carries no device code
     cur = open(os.path.join(ROOT, "profiles", "current.txt")).read().strip()
     pd = tmp_path / "profiles"
     (pd / cur).mkdir(parents=True)

@@ -290,6 +290,34 @@ def test_gpu_seq_run_below_the_abi_equals_the_python_loop(seqeng):
 
 
 @pytest.mark.gpu
+def test_gpu_seq_run_zero_ens_leading_years_and_batch_independent_bookkeeping(seqeng):
+    """relmc_seq_run: (a) while no simulated year has had curtailment the running CoV is 0 / 0 = NaN as seqMain.m:184 -- cum_cov says so,
+    the stop test (:194) rejects it, and a run that ends there returns cov = NaN (documented in relmc.h); (b) the stopping year, kernel_seconds' order
+    of magnitude and the second-attempt counters do not depend on batch_years (a batch that is cut at the stopping year is taken again over its
+    used part and the discarded pass is erased from the bookkeeping)."""
+    seed = next(s for s in range(1, 200) if seqeng.seq_years(s, 0, 2)[0].sum() == 0.0)          # a seed whose first two years lose nothing
+    lead = seqeng.seqMain(max_sim_years=2, cov_threshold=0.05, seed=seed)
+    assert lead.final_year == 2 and not lead.converged and lead.eens == 0.0 and np.isnan(lead.cov)
+    assert lead.results_cum["cov"][0] == 0.0 and np.isnan(lead.results_cum["cov"][1])
+    runs = {}
+    for by in (0, 33, 700):
+        u0 = seqeng.eng.retry_stats()
+        r = seqeng.seqMain(max_sim_years=700, cov_threshold=0.12, seed=seed, batch_years=by)
+        u1 = seqeng.eng.retry_stats()
+        runs[by] = (r, (u1[0] - u0[0], u1[1] - u0[1]))
+    r0 = runs[0][0]
+    assert r0.converged and 2 < r0.final_year < 700 and np.isnan(r0.results_cum["cov"][1]) and r0.cov < 0.12
+    first_loss = int(np.flatnonzero(r0.results_year["ens"] > 0)[0])
+    assert first_loss >= 2 and np.all(np.isnan(r0.results_cum["cov"][1:first_loss])) and np.all(np.isfinite(r0.results_cum["cov"][first_loss:]))
+    for by in (33, 700):
+        r, units = runs[by]
+        assert r.final_year == r0.final_year and r.cov == r0.cov and np.array_equal(r.results_year["ens"], r0.results_year["ens"])
+        assert units == runs[0][1]                                            # second attempts: the same units whatever the batch
+        assert r.n_lp == r0.n_lp and np.array_equal(r.acc.to_arrays()[0], r0.acc.to_arrays()[0])
+        assert 0.5 < r.kernel_seconds / r0.kernel_seconds < 2.0                # the discarded pass of a cut batch is not in kernel_seconds
+
+
+@pytest.mark.gpu
 def test_gpu_long_run_tightens_on_golden(seqeng, seq_golden):
     """20 000 simulated years (about 1.4e8 hourly OPFs): the golden means sit within the golden run's own error."""
     ens, dlc, nlc = [], [], []
