@@ -32,31 +32,35 @@ DEVFI bool screen_certify(const ScreenTab& T, const uint32_t (&m)[OW], double sc
 {
     const int ng = T.ng, nl = T.nl;
     double lo = T.sum_pmin, rg = T.sum_rng;
-    int nlo = 0, mline = 0;
+    int nlo = 0, mline = 0, nout = 0;
+    // the units out of service, one byte each (at most 16: a state with more goes to the interior point), so that the loop over the lines below
+    // walks a short list instead of scanning the mask words again for every line
+    unsigned long long list0 = 0ull, list1 = 0ull;
 #pragma unroll
     for (int q = 0; q < OW; ++q) {
         uint32_t w = m[q];
         while (w) {
             const int k = 32 * q + (__ffs((int)w) - 1);
             w &= w - 1;
-            if (k < ng) { lo -= T.pmin[k]; rg -= T.rng[k]; }
-            else { nlo += 1; mline = k - ng; }
+            if (k < ng) {
+                lo -= T.pmin[k]; rg -= T.rng[k];
+                if (nout < 8) list0 |= (unsigned long long)k << (8 * nout); else if (nout < 16) list1 |= (unsigned long long)k << (8 * (nout - 8));
+                nout += 1;
+            } else { nlo += 1; mline = k - ng; }
         }
     }
-    if (nlo > 1) return false;                                  // two or more lines out: the interior point
+    if (nlo > 1 || nout > 16) return false;                     // two or more lines out (or an improbable number of units): the interior point
     const double L = T.total_load * scale;
     if (!(lo <= L) || !(L <= lo + rg) || !(rg > 0.0)) return false;   // capacity short of the load, or over-generation at Pmin
     if (nlo == 1 && T.bridge[mline]) return false;
     const double t = (L - lo) / rg;                              // every unit in service at Pmin + t (Pmax - Pmin), 0 <= t <= 1
     auto flow = [&](int l) -> double {
         double a = T.f_min[l], b = T.f_rng[l];
-        const double* gm = T.gmin + (size_t)l * ng; const double* gr = T.grng + (size_t)l * ng;
-#pragma unroll
-        for (int q = 0; q < OW; ++q) {
-            uint32_t w = m[q];
-            if (32 * q >= ng) w = 0u;
-            else if (32 * q + 32 > ng) w &= (1u << (ng - 32 * q)) - 1u;
-            while (w) { const int k = 32 * q + (__ffs((int)w) - 1); w &= w - 1; a -= gm[k]; b -= gr[k]; }
+        const double2* g = reinterpret_cast<const double2*>(T.gpair) + (size_t)l * ng;      // {PTDF * Pmin, PTDF * range} of unit k on line l: one 16-byte load
+        for (int i = 0; i < nout; ++i) {
+            const int k = (int)(((i < 8 ? list0 >> (8 * i) : list1 >> (8 * (i - 8)))) & 0xffull);
+            const double2 v = g[k];
+            a -= v.x; b -= v.y;
         }
         return __builtin_fma(t, b, a) - scale * T.f_load[l];
     };
@@ -146,12 +150,27 @@ __global__ void __launch_bounds__(256) relmc_screen_rows_kernel(const ScreenTab 
     }
 }
 
-// seqMain.m:97-100 behind the pre-screen: the contingency hours of a year (any component down) are counted, the ones the certificate does
-// not cover -- at the hour's own load factor -- are listed in ascending order (one workgroup per year, as relmc_seq_compact_kernel)
+// seqMain.m:97-100 behind the pre-screen, in two steps.  (1) one thread per hour of the chronology: flags[h] = 0 no component down, 1 a contingency
+// hour the certificate covers at the hour's own load factor, 2 a contingency hour for the interior point.  (2) one workgroup per year (as
+// relmc_seq_compact_kernel): the count of contingency hours and the ascending list of the flag-2 hours.  (One kernel of one workgroup per year
+// that ran the certificate itself kept 125 workgroups busy for 0.72 ms per 125 years: the certificate wants the whole device.)
 template <int OW>
-__global__ void __launch_bounds__(256) relmc_seq_compact_screen_kernel(const ScreenTab T, const uint32_t* __restrict__ masks, const double* __restrict__ load_factors,
-                                                                       int hpy, uint16_t* __restrict__ hours, uint32_t* __restrict__ counts,
-                                                                       uint32_t* __restrict__ ncont)
+__global__ void __launch_bounds__(256) relmc_seq_flag_kernel(const ScreenTab T, const uint32_t* __restrict__ masks, const double* __restrict__ load_factors,
+                                                             int hpy, int64_t total_hours, uint8_t* __restrict__ flags)
+{
+    for (int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; i < total_hours; i += (int64_t)gridDim.x * blockDim.x) {
+        const uint32_t* mp = masks + (size_t)i * OW;
+        uint32_t w[OW]; uint32_t o = 0;
+#pragma unroll
+        for (int q = 0; q < OW; ++q) { w[q] = mp[q]; o |= w[q]; }
+        uint8_t f = 0;
+        if (o != 0) f = (T.valid && screen_certify<OW>(T, w, load_factors[(int)(i % hpy)])) ? 1 : 2;
+        flags[i] = f;
+    }
+}
+
+__global__ void __launch_bounds__(256) relmc_seq_compact_flags_kernel(const uint8_t* __restrict__ flags, int hpy, uint16_t* __restrict__ hours,
+                                                                      uint32_t* __restrict__ counts, uint32_t* __restrict__ ncont)
 {
     __shared__ uint32_t wsum[4], csum[4];
     __shared__ uint32_t base, cbase;
@@ -160,15 +179,8 @@ __global__ void __launch_bounds__(256) relmc_seq_compact_screen_kernel(const Scr
     __syncthreads();
     for (int h0 = 0; h0 < hpy; h0 += 256) {
         const int h = h0 + tid;
-        bool cont = false, f = false;
-        if (h < hpy) {
-            const uint32_t* mp = masks + ((size_t)y * hpy + h) * OW;
-            uint32_t w[OW]; uint32_t o = 0;
-#pragma unroll
-            for (int q = 0; q < OW; ++q) { w[q] = mp[q]; o |= w[q]; }
-            cont = o != 0;
-            f = cont && !(T.valid && screen_certify<OW>(T, w, load_factors[h]));
-        }
+        const uint8_t fl = h < hpy ? flags[(size_t)y * hpy + h] : (uint8_t)0;
+        const bool cont = fl != 0, f = fl == 2;
         const uint64_t b = __ballot(f), bc = __ballot(cont);
         const uint32_t before = (uint32_t)__popcll(b & ((1ull << lane) - 1ull));
         if (lane == 0) { wsum[wv] = (uint32_t)__popcll(b); csum[wv] = (uint32_t)__popcll(bc); }
@@ -251,10 +263,10 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
             if (i != d->ref_bus && j != d->ref_bus) X[(size_t)i * nb + j] = B[(size_t)red(i) * n + red(j)];
     }
     auto ptdf = [&](int l, int bus) { return d->br_b[l] * (X[(size_t)d->br_from[l] * nb + bus] - X[(size_t)d->br_to[l] * nb + bus]); };
-    const size_t n_d = (size_t)2 * ng + (size_t)4 * nl + (size_t)2 * nl * ng + (size_t)nl * nl;
+    const size_t n_d = (size_t)2 * ng + (size_t)4 * nl + (size_t)2 * nl * ng + (size_t)nl * nl;       // the pair table starts 16-byte aligned (2 ng + 4 nl doubles before it)
     std::vector<double> h(n_d, 0.0);
     double* pmin = h.data(); double* rng = pmin + ng; double* f_min = rng + ng; double* f_rng = f_min + nl; double* f_load = f_rng + nl; double* lim = f_load + nl;
-    double* gmin = lim + nl; double* grng = gmin + (size_t)nl * ng; double* lodf = grng + (size_t)nl * ng;
+    double* gpair = lim + nl; double* lodf = gpair + (size_t)2 * nl * ng;
     std::vector<uint8_t> bridge((size_t)nl, 0);
     double sum_pmin = 0.0, sum_rng = 0.0;
     for (int k = 0; k < ng; ++k) {
@@ -268,7 +280,7 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
         double a = 0.0, b = 0.0, c = 0.0;
         for (int k = 0; k < ng; ++k) {
             const double p = ptdf(l, d->inj_bus[k]);
-            gmin[(size_t)l * ng + k] = p * pmin[k]; grng[(size_t)l * ng + k] = p * rng[k];
+            gpair[2 * ((size_t)l * ng + k)] = p * pmin[k]; gpair[2 * ((size_t)l * ng + k) + 1] = p * rng[k];
             a += p * pmin[k]; b += p * rng[k];
         }
         for (int i = 0; i < nb; ++i) c += ptdf(l, i) * d->bus_pd[i];
@@ -290,7 +302,7 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
     const double* dd = reinterpret_cast<const double*>(S.dtab);
     S.tab.sum_pmin = sum_pmin; S.tab.sum_rng = sum_rng;
     S.tab.pmin = dd; S.tab.rng = dd + ng; S.tab.f_min = dd + 2 * ng; S.tab.f_rng = S.tab.f_min + nl; S.tab.f_load = S.tab.f_rng + nl; S.tab.lim = S.tab.f_load + nl;
-    S.tab.gmin = S.tab.lim + nl; S.tab.grng = S.tab.gmin + (size_t)nl * ng; S.tab.lodf = S.tab.grng + (size_t)nl * ng;
+    S.tab.gpair = S.tab.lim + nl; S.tab.lodf = S.tab.gpair + (size_t)2 * nl * ng;
     S.tab.bridge = reinterpret_cast<const uint8_t*>(dd + n_d);
     S.tab.valid = 1;
     return RELMC_OK;
@@ -376,10 +388,20 @@ int screen_prepass_rows(relmc_ctx* ctx, int64_t first, int64_t n, uint32_t* n_su
 // seqMain.m:97-100 with the certificate: per year the count of contingency hours (ncont) and the listed hours the certificate does not cover (counts)
 int screen_seq_compact(relmc_ctx* ctx, const uint32_t* masks, int n_years, uint16_t* hours, uint32_t* counts, uint32_t* ncont)
 {
+    // (timed between the context's screen events: relmc_seq_years adds it to the device time it reports once the stream has been synchronised)
     const int hpy = ctx->hseq.hpy;
-    if (ctx->tile == 0) hipLaunchKernelGGL(relmc_seq_compact_screen_kernel<Tile24::OW>, dim3(n_years), dim3(256), 0, ctx->stream, ctx->screen.tab, masks, ctx->dlf, hpy, hours, counts, ncont);
-    else hipLaunchKernelGGL(relmc_seq_compact_screen_kernel<Tile96::OW>, dim3(n_years), dim3(256), 0, ctx->stream, ctx->screen.tab, masks, ctx->dlf, hpy, hours, counts, ncont);
+    const int64_t total = (int64_t)n_years * hpy;
+    int rc = screen_buffers(ctx, total);
+    if (rc) return rc;
+    auto& S = ctx->screen;
+    const int64_t g = grid256(ctx, total);
+    HIP_TRY(ctx, hipEventRecord(S.ev0, ctx->stream));
+    if (ctx->tile == 0) hipLaunchKernelGGL(relmc_seq_flag_kernel<Tile24::OW>, dim3((unsigned)g), dim3(256), 0, ctx->stream, S.tab, masks, ctx->dlf, hpy, total, S.flags);
+    else hipLaunchKernelGGL(relmc_seq_flag_kernel<Tile96::OW>, dim3((unsigned)g), dim3(256), 0, ctx->stream, S.tab, masks, ctx->dlf, hpy, total, S.flags);
     HIP_TRY(ctx, hipGetLastError());
+    hipLaunchKernelGGL(relmc_seq_compact_flags_kernel, dim3(n_years), dim3(256), 0, ctx->stream, S.flags, hpy, hours, counts, ncont);
+    HIP_TRY(ctx, hipGetLastError());
+    HIP_TRY(ctx, hipEventRecord(S.ev1, ctx->stream));
     return RELMC_OK;
 }
 

@@ -157,6 +157,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
     }
     const int64_t nlp = off[n_years];
     double ms = 0.0;
+    if (screen) { float t = 0.f; if (hipEventElapsedTime(&t, ctx->screen.ev0, ctx->screen.ev1) == hipSuccess) ms += t; }      // the certificate's pre-pass (the stream was synchronised above)
     if (nlp > 0) {
         if (hipMemcpyAsync(doff, off.data(), sizeof(uint32_t) * (n_years + 1), hipMemcpyHostToDevice, ctx->stream) != hipSuccess) { cleanup(); return fail(ctx, RELMC_ERR_HIP, "relmc_seq_years: H2D failed"); }
         EvalArgs a = make_args(o);
@@ -175,7 +176,7 @@ int32_t relmc_seq_years(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int3
         if (rc) { cleanup(); return rc; }
         *acc_out = ctx->hstage->acc;
         const uint32_t listed = a.fail_count ? ctx->hstage->fail_cnt : 0u;
-        ms = ctx->last_kernel_ms;
+        ms += ctx->last_kernel_ms;
         RetryOut ro;                                                   // hours the primary elimination order did not converge on
         const ScaleFn scale = [&](unsigned long long u) { return ctx->hlf[(size_t)(u % (unsigned long long)hpy)]; };
         rc = fail_retry(ctx, o, curtail_threshold, &scale, ro, &ms, a.fail_count ? &listed : nullptr);

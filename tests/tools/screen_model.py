@@ -50,7 +50,7 @@ def certify(case, ptdf, lodf, states, load_scale=1.0, margin=1e-9, max_lines_out
     scale = np.broadcast_to(np.asarray(load_scale, dtype=np.float64), (n,))
     L = case.total_load * scale
     lo = on @ pmin; hi = on @ pmax
-    ok = (lo <= L) & (L <= hi) & (hi > lo)
+    ok = (lo <= L) & (L <= hi) & (hi > lo) & (st[:, :ng].sum(1) <= 16)        # the device keeps the units out in a 16-entry list; more: not certified
     t = np.where(ok, (L - lo) / np.where(hi > lo, hi - lo, 1.0), 0.0)
     pg = on * (pmin[None, :] + t[:, None] * (pmax - pmin)[None, :])
     Cg = np.zeros((ng, nb)); Cg[np.arange(ng), case.inj_bus[:ng]] = 1.0
