@@ -118,11 +118,13 @@ function Engine(sys::TestSystem; device::Integer=0, elim_order::Union{Nothing,Ve
     return eng
 end
 
-"mpoption('PF_DC',1,...,'OPF_ALG_DC',200,'OPF_FLOW_LIM',1) of nsqMain.m:185-186 = MIPS defaults."
-function mpoption(; singular_policy::Integer=0)
+"mpoption('PF_DC',1,...,'OPF_ALG_DC',200,'OPF_FLOW_LIM',1) of nsqMain.m:185-186 = MIPS defaults.  screen = 1: the zero-curtailment pre-screen
+(relmc.h: states with a proven LP optimum of 0 are counted, not solved; Acc.n_screened counts them; every other output unchanged)."
+function mpoption(; singular_policy::Integer=0, screen::Integer=0)
     o = SolverOpts()
     ccall((:relmc_solver_opts_default, LIB), Cvoid, (Ref{SolverOpts},), o)
     o.singular_policy = singular_policy
+    o.screen = screen
     return o
 end
 

@@ -3,17 +3,22 @@
  * mc_sampling + mc_simulation hot path.  Only tests/, __graft_entry__.smoke() and bench.py's
  * cpu_baseline leg may load this library; the product (include/relmc.h) never does.
  *
- * PARITY UNPINNED per state: the arithmetic of the path lives in MATPOWER (runopf ->
- * dcopf_solver -> qps_mips -> mips; call site Montecarlo_nsq_single/mc_simulation.m:41), an
- * un-vendored and un-pinned dependency of the reference (README.md:46-48), and the reference
- * holds no tests or per-state vectors.  This file restates MATPOWER's published algorithm
- *  on the UNREDUCED formulation — variables [Va; Pg], MIPS' own
- * equality/inequality split, the full (nx+neq) KKT system solved by LU with partial pivoting,
- * as MATLAB's `\` would — so that it is independent of the reduced in-register elimination the
- * HIP kernels use.  It is pinned (a) per state against scipy/HiGHS LP values and the numpy
- * MIPS of oracle/pyoracle.py (tests/golden/states_fixture.json), (b) statistically against the
- * reference's golden artifacts reliability_results.mat / nodal_results.csv
- * (tests/golden/nsq_golden.json).
+ * PARITY PIN.  The arithmetic of the path lives in MATPOWER (runopf -> dcopf_solver -> qps_mips -> mips; call site
+ * Montecarlo_nsq_single/mc_simulation.m:41), an un-vendored and un-pinned dependency of the reference (README.md:46-48), and the
+ * reference holds no tests and no per-state vectors: no single state's (dns, nodal, iterations) can be compared with the reference's.
+ * This file restates MATPOWER's published algorithm on the UNREDUCED formulation — variables [Va; Pg], MIPS'
+ * own equality/inequality split, the full (nx+neq) KKT system solved by LU with partial pivoting, as MATLAB's `\` would — so that it
+ * is independent of the reduced in-register elimination the HIP kernels use.  What pins it:
+ *  (a) per state: scipy/HiGHS LP values and the numpy MIPS of oracle/pyoracle.py (tests/golden/states_fixture.json);
+ *  (b) the reference's golden artifacts reliability_results.mat / nodal_results.csv (tests/golden/nsq_golden.json), as joint statistics
+ *      of the converged means (tests/golden_stats.py: nodal vector, importance vector, (EDNS, PLC));
+ *  (c) round 6 — WHERE THE INTERIOR POINT STOPS, from reference-held data: edns_history / beta_history reconstruct the golden run's
+ *      1 000 per-batch sums of dns and dns^2; every batch sum is whole MW plus the sum of MIPS' termination residuals f + 2850 over the
+ *      batch's shed samples (2.332e-07 MW per shed sample).  This oracle reproduces that distribution (two-sample KS p = 0.36, mean
+ *      residual within 0.02 %), and the same statistic rejects comptol x or / 10, sigma = 0.2, xi = 0.9995, z0 = 2 at p < 1e-70
+ *      (tests/test_oracle.py): the recalled MIPS constants and the start point are pinned by the reference's own vectors.  34 golden
+ *      batches carry one sample of 1 434 +- 16 MW: the isolated-bus state's dns = load / 2 = 1 425 MW of REFERENCE_EMULATE, read off the
+ *      golden histories (PHYSICAL rejected at p = 7e-50).
  *
  * Reference lines followed:
  *   mc_sampling.m:24-41      -> orc_mc_sampling (counter-based RNG instead of rand, strict '<')

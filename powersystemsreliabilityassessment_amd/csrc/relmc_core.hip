@@ -282,7 +282,7 @@ using namespace relmc_host;
 
 extern "C" {
 
-const char* relmc_version(void) { return "relmc 0.8 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules with a tunable elimination order + dense pivoted last resort, device state database, nsqMain and seqMain loops below the ABI, guarded collectives)"; }
+const char* relmc_version(void) { return "relmc 0.9 (gfx950; DPP-row IPM tiles 16x4 and 64x1, sparse 2x2-block LDL' in LDS, static schedules with a tunable elimination order + dense pivoted last resort, device state database, zero-curtailment pre-screen, nsqMain and seqMain loops below the ABI with checkpoint stretches over N ranks, guarded collectives)"; }
 
 const char* relmc_last_error(const relmc_ctx* ctx) { return ctx ? ctx->err.c_str() : kNoCtx; }
 
