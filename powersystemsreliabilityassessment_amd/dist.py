@@ -10,6 +10,8 @@ the number of ranks (integers exactly, fp64 sums up to summation order).
 """
 from __future__ import annotations
 
+import math
+
 import numpy as np
 
 from . import _abi
@@ -316,6 +318,77 @@ def nsq_run_distributed(accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, be
         beta = idx["beta"]
         hist.append((done, beta, idx["edns"], idx["lole"], idx["plc"]))
     return idx, total, hist
+
+
+def nsq_run_stretches(sample_dns_fn, accumulate_fn, nb: int, ncomp: int, *, seed: int = 1, beta_limit: float = 0.0017, max_samples: int = 100000,
+                      batch: int = 100, hours_per_year: float = 8760.0, rank: int | None = None, world: int | None = None, round_samples: int = 8192):
+    """Python restatement of relmc_nsq_run's CHECKPOINT STRETCHES over `world` ranks (csrc/relmc_simulate.hip): what the CPU gloo
+    test checks the stretch arithmetic with (which checkpoints two ranks share, the packed all-reduce, the cut-and-retake rule).
+
+    sample_dns_fn(seed, first, n) -> dns of every sample of the range in sampling order; accumulate_fn(seed, first, n) -> _abi.Acc.
+    Every rank evaluates its contiguous slice of a stretch, folds it into per-checkpoint partial (sum dns, sum dns^2, losses) triples, ONE all-reduce
+    of [3 x checkpoints | accumulators as doubles] per stretch; all ranks walk the checkpoints and stop at the same one; a cut stretch is taken again
+    over its used part.  Returns (indices dict, merged Acc, history list, number of collectives)."""
+    import torch
+    import torch.distributed as dist
+    if rank is None or world is None:
+        rank, world = (dist.get_rank(), dist.get_world_size()) if dist.is_available() and dist.is_initialized() else (0, 1)
+    per = (1 << 18) // batch * batch
+    n_coll = 0
+
+    def shared(lo0, ln, with_trip):
+        nonlocal n_coll
+        lo, cnt = shard_range(lo0, ln, rank, world)
+        ncp = -(-ln // batch) if with_trip else 0
+        box = np.zeros(3 * ncp + _abi.Acc.N_INT + _abi.Acc.N_DBL)
+        part = accumulate_fn(seed, lo, cnt) if cnt > 0 else _abi.Acc()
+        if with_trip and cnt > 0:
+            d = np.asarray(sample_dns_fn(seed, lo, cnt), dtype=np.float64)
+            k = (lo - lo0 + np.arange(cnt)) // batch
+            np.add.at(box, 3 * k, d); np.add.at(box, 3 * k + 1, d * d); np.add.at(box, 3 * k + 2, (d > 1e-4).astype(np.float64))
+        ai, ad = part.to_arrays()
+        box[3 * ncp:3 * ncp + ai.size] = ai.astype(np.float64); box[3 * ncp + ai.size:] = ad
+        if world > 1:
+            t = torch.from_numpy(box); dist.all_reduce(t, op=dist.ReduceOp.SUM); n_coll += 1
+        ints = np.rint(box[3 * ncp:3 * ncp + ai.size]).astype(np.int64)
+        return box[:3 * ncp].reshape(-1, 3), _abi.Acc.from_arrays(ints, box[3 * ncp + ai.size:])
+
+    total, done, beta, hist = _abi.Acc(), 0, float("inf"), []
+    first = max(25600 // batch * batch, batch); least = max(1600 // batch * batch, batch)
+    while beta > beta_limit and done < max_samples:
+        ln = done // batch * batch if done > first else first
+        final = False
+        if done > 0 and beta_limit > 0 and beta < 1e6 and beta > beta_limit:
+            need = done * (beta / beta_limit) ** 2
+            target = 0.9 * need if done < 0.85 * need else 1.03 * need
+            l = math.ceil((target - done) / batch) * batch
+            ln = least if l < least else (per if l > per else int(l))
+            final = not (done < 0.85 * need)
+        ln = min(ln, per)
+        if not final:
+            snapped = (ln // round_samples) * round_samples // batch * batch
+            if ln >= 2 * round_samples and snapped >= least:
+                ln = snapped
+        m = min(max_samples - done, ln)
+        trip, part = shared(done, m, True)
+        run_n, run_f, run_s, run_s2 = int(total.n), int(total.n_fail), float(total.sum_dns), float(total.sum_dns2)
+        used = 0
+        for k in range(trip.shape[0]):
+            b = min(batch, m - used)
+            run_n += b; run_f += int(round(trip[k, 2])); run_s += trip[k, 0]; run_s2 += trip[k, 1]; used += b
+            e = run_s / run_n; ss = max(run_s2 - run_n * e * e, 0.0)
+            beta = math.sqrt(ss) / run_n / e if e > 0 else float("inf")
+            hist.append((done + used, beta, e, run_f / run_n * hours_per_year, run_f / run_n))
+            if beta <= beta_limit:
+                break
+        if used < m:
+            _, part = shared(done, used, False)
+        total = merge(total, part)
+        done += used
+        idx = indices_from_acc(total, nb, ncomp, hours_per_year)
+        beta = idx["beta"]
+        hist[-1] = (done, beta, idx["edns"], idx["lole"], idx["plc"])
+    return indices_from_acc(total, nb, ncomp, hours_per_year), total, hist, n_coll
 
 
 def allgather_years(arr: np.ndarray, counts, device=None) -> np.ndarray:

@@ -149,6 +149,55 @@ def test_distributed_driver_gloo_world2(tmp_path, oracle):
     assert float(got["beta"]) <= 0.02 or n >= 60000
 
 
+_STRETCH_WORKER = r"""
+import os, sys
+sys.path.insert(0, {root!r})
+import numpy as np, torch.distributed as dist
+from powersystemsreliabilityassessment_amd import case24, dist as rdist
+from oracle import coracle
+rank, world = int(sys.argv[1]), int(sys.argv[2])
+if world > 1:
+    os.environ.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=sys.argv[3], RANK=str(rank), WORLD_SIZE=str(world))
+    dist.init_process_group("gloo", rank=rank, world_size=world)
+case = case24.rts24(); orc = coracle.Oracle(case)
+acc_fn = lambda seed, first, n: orc.nsq_accumulate(seed, first, n, 0, nthreads=4)
+dns_fn = lambda seed, first, n: orc.mc_simulation(orc.mc_sampling(seed, first, n), 0, nthreads=4)["dns"]
+idx, total, hist, ncoll = rdist.nsq_run_stretches(dns_fn, acc_fn, case.nb, case.ncomp, seed=1, beta_limit=0.03, max_samples=200000, batch=100,
+                                                  rank=rank, world=world)
+if rank == 0:
+    ti, td = total.to_arrays()
+    np.savez(sys.argv[4], ti=ti, td=td, hist=np.array(hist), ncoll=ncoll)
+if world > 1:
+    dist.destroy_process_group()
+"""
+
+
+def test_checkpoint_stretches_gloo_world2(tmp_path, oracle):
+    """relmc_nsq_run's checkpoint stretches over N ranks, restated in Python (dist.nsq_run_stretches) with the oracle as the evaluator: two
+    gloo ranks at the reference's spacing of 100 samples stop at the ONE-rank run's checkpoint -- the checkpoint the oracle's own batch-by-batch
+    database loop stops at --, with its history and accumulators, in one collective per stretch (+ one for the cut)."""
+    script = tmp_path / "stretch.py"
+    script.write_text(_STRETCH_WORKER.format(root=ROOT))
+    o2, o1 = tmp_path / "w2.npz", tmp_path / "w1.npz"
+    port = str(29300 + os.getpid() % 90)
+    procs = [subprocess.Popen([sys.executable, str(script), str(r), "2", port, str(o2)]) for r in range(2)]
+    one = subprocess.Popen([sys.executable, str(script), "0", "1", "0", str(o1)])
+    for p in procs + [one]:
+        assert p.wait(timeout=900) == 0
+    g2, g1 = np.load(o2), np.load(o1)
+    h2, h1 = g2["hist"], g1["hist"]
+    assert h2.shape == h1.shape and np.array_equal(h2[:, 0], h1[:, 0]) and np.array_equal(h2[:, 4], h1[:, 4])      # same checkpoints, same loss counts
+    np.testing.assert_allclose(h2[:, 1:4], h1[:, 1:4], rtol=1e-11)
+    assert np.array_equal(g2["ti"], g1["ti"])
+    np.testing.assert_allclose(g2["td"], g1["td"], rtol=1e-11, atol=1e-9)
+    n = int(h1[-1, 0])
+    assert h1[-1, 1] <= 0.03 < h1[-2, 1] and n % 100 == 0 and int(g2["ncoll"]) in (2, 3, 4) and int(g1["ncoll"]) == 0
+    ref = oracle.nsq_database(1, beta_limit=0.03, max_iterations=200000, samples_per_batch=100, nthreads=8)          # nsqMain.m:208-308 batch by batch
+    assert ref["iterations"] == n and len(ref["beta_history"]) == h1.shape[0]
+    np.testing.assert_allclose(h1[:, 1], ref["beta_history"], rtol=1e-9)
+    np.testing.assert_allclose(h1[:, 2], ref["edns_history"], rtol=1e-11)
+
+
 _AR_WORKER = r"""
 import os, sys
 sys.path.insert(0, {root!r})
