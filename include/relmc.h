@@ -103,7 +103,8 @@ typedef struct {
                                  for which an explicit dispatch serves all load -- units in service loaded proportionally between Pmin and Pmax, DC
                                  flows through the base-topology PTDF (one line out: + its LODF column) inside every rating -- has LP optimum 0, so the
                                  reference's outputs for it are exactly (0, zeros) (mc_simulation.m:57-59, 65) and it is counted without being solved.
-                                 Every output but the iteration statistics is the one of screen = 0; relmc_acc.n_screened counts the skipped units.
+                                 Every output but the iteration statistics is the one of screen = 0 (of its converged solves: a unit the interior point
+                                 would have left non-converged is counted with the proven optimum); relmc_acc.n_screened counts the skipped units.
                                  Honoured by the fused pass (relmc_nsq_accumulate, relmc_nsq_run), by the new rows of the state database
                                  (relmc_nsq_db_batch: a certified row carries 0 iterations) and by the sequential track's contingency hours at
                                  their own load factor (relmc_seq_years, relmc_seq_run); relmc_mc_simulation and relmc_nsq_accumulate_distinct

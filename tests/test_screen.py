@@ -257,3 +257,44 @@ def test_screened_random_networks(model):
                 np.testing.assert_allclose(db, da, rtol=1e-12, atol=1e-9)
         finally:
             eng.close()
+
+
+@pytest.mark.gpu
+def test_screen_with_second_attempts_and_on_a_case_without_a_certificate(engine, case):
+    """(a) The survivors' unit numbers through the retry list (MODE 7: a listed unit is named by its sample offset): with an iteration limit of 7 every
+    solved unit goes to the further orders and comes back non-converged -- the per-sample dns behind the histories is mc_simulation's for the uncovered
+    samples and 0 for the certified ones.  (b) A case whose base topology is not one island (RTS-24 without the branch that holds bus 7) has no PTDF: the pre-screen then
+    certifies nothing and screen = 1 is screen = 0."""
+    import dataclasses
+    import golden_stats as gs
+    # an iteration limit of 7 ends every solved unit non-converged (twice: the further orders do no better).  The identity with screen = 0 is a statement
+    # about CONVERGED solves -- a certified unit is counted with its proven optimum 0, not with the last iterate of a solve that was cut short -- so the
+    # reference here is mc_simulation of the same samples under the same limit, with the certified ones set to 0
+    o0, o1 = api.mpoption(max_it=7), api.mpoption(max_it=7, screen=1)
+    n = 20_000
+    st = engine.mc_sampling(None, n, seed=5)
+    cert = engine.screen_states(st)
+    dns, _, info = engine.mc_simulation(st, mpopt=o0, return_info=True)
+    assert np.all(info["status"][~cert] != 0) and 0.85 < cert.mean() < 0.95
+    want = np.where(cert, 0.0, dns)
+    u0 = engine.retry_stats()
+    rb = engine.nsqMain(beta_limit=0.0, max_iterations=n, samples_per_batch=100, seed=5, mpopt=o1)
+    u1 = engine.retry_stats()
+    solved = ~cert & (info["status"] != 3)                       # isolated-bus states are not iterated under REFERENCE_EMULATE
+    assert u1[0] - u0[0] == int(solved.sum()) and rb.n_screened == int(cert.sum()) and rb.n_nonconverged == int(solved.sum())
+    np.testing.assert_allclose(gs.batch_sums(rb.edns_history, 100), want.reshape(-1, 100).sum(1), rtol=1e-7, atol=1e-4)       # every listed unit came back to ITS sample (a misplaced one would move a batch by ~100 MW; the last iterate of a cut-short solve is not good to 1e-9)
+    assert rb.acc.n_fail == int((want > 1e-4).sum())
+    keep = np.arange(case.nl) != 10
+    cut = dataclasses.replace(case, nl=case.nl - 1, br_from=case.br_from[keep], br_to=case.br_to[keep], br_b=case.br_b[keep], br_rate=case.br_rate[keep],
+                              unavail=np.concatenate([case.unavail[:case.ng], case.unavail[case.ng:][keep]]),
+                              always_up=np.concatenate([case.always_up[:case.ng], case.always_up[case.ng:][keep]]), elim_order=None)
+    eng = api.Engine(cut)
+    try:
+        st = eng.mc_sampling(None, 2000, seed=3)
+        assert not eng.screen_states(st).any()
+        for pol in (api.REFERENCE_EMULATE, api.PHYSICAL):
+            x, y = eng.nsq_accumulate(3, 0, 20_000, api.mpoption(pol)), eng.nsq_accumulate(3, 0, 20_000, api.mpoption(pol, screen=1))
+            assert np.array_equal(x.to_arrays()[0], y.to_arrays()[0]) and y.n_screened == 0
+            assert np.array_equal(x.to_arrays()[1], y.to_arrays()[1])               # the very same launches: bit for bit
+    finally:
+        eng.close()
