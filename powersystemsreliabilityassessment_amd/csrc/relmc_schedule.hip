@@ -715,7 +715,8 @@ int32_t relmc_tune_order(const relmc_case_desc* d, int32_t evaluations, uint64_t
 // case under elimination order `order_variant` (0 = primary).  tests/test_schedule.py interprets the schedule on the CPU against a dense
 // solve, which is how every ordering / scheduling change is checked before it reaches a GPU.
 //   hdr[24]: tile (0 = 16-lane rows, 1 = 64-lane rows), RW, nb, noff, nws, off_rhs, npass, npass_upd, npass_inv, npass_updh, npass_updq,
-//            nzero, scen_doubles, lds_bytes, modelled LDS conflict cycles before / after the placement search, MAXPASS, nl, 6 spare
+//            nzero, scen_doubles, lds_bytes, modelled LDS conflict cycles before / after the placement search, MAXPASS, nl, flags, bwd_half (2), longest line / injection
+//            list per bus slot (4 bytes), 2 spare
 //   tasks[npass][RW][4] (0xffff = no task), pass_ntask[npass], b_int[nb] (external -> internal bus), l_blk[nl] (W offset of the owner
 //   line's block, 0xffff otherwise), l_info[nl] (from | to << 8 | flags << 24, internal bus numbers), zero_off[nzero]
 int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, const int32_t* order_hint, int32_t n_hint, int32_t* hdr, uint16_t* tasks, int64_t tasks_cap, uint8_t* pass_ntask,
@@ -734,6 +735,7 @@ int32_t relmc_debug_symbolic(const relmc_case_desc* d, int32_t order_variant, co
         hdr[8] = C.npass_inv; hdr[9] = C.npass_updh; hdr[10] = C.npass_updq; hdr[11] = C.nzero; hdr[12] = (int)g.scen_doubles; hdr[13] = (int)g.lds_bytes;
         hdr[14] = (int)g.conflict_before; hdr[15] = (int)g.conflict_after; hdr[16] = maxpass; hdr[17] = C.nl;
         hdr[19] = (int32_t)(uint32_t)(C.bwd_half & 0xffffffffull); hdr[20] = (int32_t)(uint32_t)(C.bwd_half >> 32);
+        hdr[21] = (int32_t)((uint32_t)C.maxdeg_s[0] | ((uint32_t)C.maxdeg_s[1] << 8) | ((uint32_t)C.maxinj_s[0] << 16) | ((uint32_t)C.maxinj_s[1] << 24));   // longest line / injection list per bus slot
         if ((int64_t)C.npass * rw * 4 > tasks_cap) return (int)RELMC_ERR_INVALID;
         for (int p = 0; p < C.npass; ++p) { pass_ntask[p] = C.pass_ntask[p]; for (int r = 0; r < rw; ++r) for (int k = 0; k < 4; ++k) {
             // back to offsets in doubles (what tests/schedule_interp.py executes); bit 15 of field 0 of a full-form update pass is the rhs flag

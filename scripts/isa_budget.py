@@ -342,6 +342,25 @@ def budget(D, T):
     if second is not None:
         for i in own[ipm]:
             if pos[i] > second: fb[i] *= (T - 1.0) / T
+    # the unrolled incidence-list gathers of the assembly (two bus slots x {line list, injection list}, two entries per step, `if (e >= longest) break`):
+    # four runs of four wave-uniform `s_cbranch_vccnz` exits in the loop's own code; step k runs while 2k < the longest list of the slot
+    runs, cur = [], []
+    for b in blocks:
+        if b.idx in own[ipm] and b.ins and b.ins[-1][0] == "s_cbranch_vccnz" and any(op.startswith("ds_read") for op, _ in b.ins + blocks[b.idx + 1].ins):
+            if cur and b.idx - cur[-1] > 1: runs.append(cur); cur = []
+            cur.append(b.idx)
+        elif cur and b.idx - cur[-1] > 1:
+            runs.append(cur); cur = []
+    if cur: runs.append(cur)
+    runs = [r for r in runs if len(r) == 4]
+    S = D["S"]
+    D["gather_runs"] = len(runs)
+    if len(runs) == 4:
+        longest = [S.maxdeg[0], S.maxinj[0], S.maxdeg[1], S.maxinj[1]]
+        for r, ln in zip(runs, longest):
+            for k in range(4):                          # the code of step k sits behind exit k: in the block that ends with exit k + 1 (the last step: the fall-through block)
+                if not (2 * k < ln):
+                    fb[r[k] + 1] = 0.0
     total = collections.Counter(); region = collections.defaultdict(collections.Counter)
     for b in blocks:
         if b.idx not in fb: continue
@@ -436,23 +455,20 @@ def per_trip(tile, D, it_lo, it_hi, out_md=None):
     a, b = json.load(open(it_lo)), json.load(open(it_hi))
     P = D["P"]
     groups_total = P["n"] / P["rows"]
-    budget(D, 1e9)                                   # T -> infinity: (T - 1) / T = 1, frequencies relative to the loop's own trip follow below
+    _, _, fb = budget(D, 1e9)                        # T -> infinity: (T - 1) / T = 1, frequencies relative to the loop's own trip follow below
     blocks, loops, own, parent, ipm = D["blocks"], D["loops"], D["own"], D["parent"], D["ipm"]
     f_ipm = D["freq_loop"][ipm]
-    innermost = {}
-    for h in loops:
-        for i in own[h]: innermost[i] = h
     tot = collections.Counter()
     for i in loops[ipm]:
-        h = innermost[i]
-        f = D["freq_loop"][h] / f_ipm
+        f = fb[i] / f_ipm
         for op, text in blocks[i].ins:
             tot[classify(op, text)] += f
     L = []; pr = L.append
     pr(f"# One trip of the interior-point loop of relmc_eval_kernel<0, Tile{tile}>, per wavefront ({P['rows']} scenario row(s))")
     pr("")
     pr(f"Static: the loop's basic blocks x the static schedule's pass counts ({D['trips_pass'][0]} full + {D['trips_pass'][1]} half + {D['trips_pass'][2]} quarter update passes, "
-       f"{D['trips_pass'][3]} inversion, {D['trips_pass'][4]} back-substitution), every conditional region counted as taken.  Measured: rocprofv3 --pmc counters of two "
+       f"{D['trips_pass'][3]} inversion, {D['trips_pass'][4]} back-substitution); the unrolled incidence-list gathers run the steps the case's longest lists ask for "
+       f"(lines {D['S'].maxdeg[0]} / {D['S'].maxdeg[1]}, injections {D['S'].maxinj[0]} / {D['S'].maxinj[1]} per bus slot: {D['gather_runs']} of 4 gather runs found in the assembly); every other conditional region counted as taken.  Measured: rocprofv3 --pmc counters of two "
        f"{P['n']}-scenario launches in which every row stops after {int(a['mean_max_iters'])} and {int(b['mean_max_iters'])} Newton steps (mpoption(max_it), no second attempts), "
        f"difference / {groups_total:.0f} wavefront-groups.")
     pr("")

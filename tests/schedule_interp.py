@@ -45,6 +45,8 @@ class Schedule:
     l_blk: np.ndarray          # [nl] W offset of the owner line's block (0xffff: not an owner)
     l_info: np.ndarray
     zero_off: np.ndarray
+    maxdeg: tuple = (0, 0)     # longest line list among the buses of bus slot 0 / 1 (the gathers' unrolled steps stop there)
+    maxinj: tuple = (0, 0)     # longest injection list per bus slot
 
     @property
     def npass_bwd(self):
@@ -77,7 +79,8 @@ def symbolic(case, order_variant: int = 0, order=None, model_leaf_free: int = -1
                     npass_updh=h[9], npass_updq=h[10], nzero=h[11], scen_doubles=h[12], lds_bytes=h[13], conflict_before=h[14],
                     conflict_after=h[15], nl=h[17], flags=h[18], bwd_half=(h[19] & 0xffffffff) | ((h[20] & 0xffffffff) << 32),
                     tasks=tasks[: npass * rw * 4].reshape(npass, rw, 4).copy(), pass_ntask=pnt[:npass].copy(), b_int=b_int[: h[2]].copy(),
-                    l_blk=l_blk[: h[17]].copy(), l_info=l_info[: h[17]].copy(), zero_off=zero_off[: h[11]].copy())
+                    l_blk=l_blk[: h[17]].copy(), l_info=l_info[: h[17]].copy(), zero_off=zero_off[: h[11]].copy(),
+                    maxdeg=(h[21] & 0xff, (h[21] >> 8) & 0xff), maxinj=((h[21] >> 16) & 0xff, (h[21] >> 24) & 0xff))
 
 
 def random_system(s: Schedule, rng, line_on=None):
