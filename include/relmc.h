@@ -230,7 +230,8 @@ int32_t relmc_last_kernel_ms(const relmc_ctx* ctx, double* ms);
  *   relmc_db_size        rows and samples held
  *   relmc_db_export      rows [first_row, first_row + n_rows) in the reference's column layout; any output may be NULL:
  *                        states[n x (ng+nl)], count[n], dns[n], flag[n] (dns > 1e-4, :270), nodal[n x nb], status[n], iters[n],
- *                        relaxed[n] (1 = an island rule relaxed Pmin or decommitted units: the row counts in n_infeasible)
+ *                        relaxed[n] (bit 0 = an island rule relaxed Pmin or decommitted units: the row counts in n_infeasible; bit 1 = the row was
+ *                        certified by the pre-screen and never solved: it counts in n_screened)
  *   relmc_db_import      resume: exported rows back into an EMPTY database, same order (the table of row ids is rebuilt); the next
  *                        relmc_nsq_db_batch / relmc_nsq_run(distinct_states = 2) continues as if the run had never stopped.
  *                        opts = the solver options the rows were computed under (NULL = defaults); status / iters / relaxed may be NULL

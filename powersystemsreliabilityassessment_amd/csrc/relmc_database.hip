@@ -476,7 +476,7 @@ int32_t relmc_db_export(relmc_ctx* ctx, int64_t first_row, int64_t n_rows, uint8
         if (flag_host) flag_host[r] = dns[r] > 1e-4 ? 1 : 0;                  // nsqMain.m:270
         if (status_host) status_host[r] = meta[r] & 3;
         if (iters_host) iters_host[r] = (int32_t)((uint32_t)meta[r] >> 8);
-        if (relaxed_host) relaxed_host[r] = (uint8_t)((meta[r] >> 2) & 1);
+        if (relaxed_host) relaxed_host[r] = (uint8_t)((meta[r] >> 2) & 3);        // bit 0: an island needed Pmin relaxation / decommit; bit 1: certified by the pre-screen, never solved
     }
     return RELMC_OK;
 }
@@ -504,7 +504,7 @@ int32_t relmc_db_import(relmc_ctx* ctx, const relmc_solver_opts* opts, int64_t n
         for (int k = 0; k < ncomp; ++k) if (states_host[r * ncomp + k]) keys[r * ow + (k >> 5)] |= 1u << (k & 31);
         if (count_host[r] <= 0) return fail(ctx, RELMC_ERR_INVALID, "relmc_db_import: a row with a count below 1");
         cnt[r] = (unsigned long long)count_host[r]; samples += count_host[r];
-        meta[r] = (status_host ? (status_host[r] & 3) : 0) | ((relaxed_host && relaxed_host[r]) ? 4 : 0) | ((iters_host ? iters_host[r] : 0) << 8);
+        meta[r] = (status_host ? (status_host[r] & 3) : 0) | ((relaxed_host && (relaxed_host[r] & 1)) ? 4 : 0) | ((relaxed_host && (relaxed_host[r] & 2)) ? 8 : 0) | ((iters_host ? iters_host[r] : 0) << 8);
     }
     HIP_TRY(ctx, hipMemcpyAsync(ctx->db_keys, keys.data(), sizeof(uint32_t) * n * ow, hipMemcpyHostToDevice, ctx->stream));
     HIP_TRY(ctx, hipMemcpyAsync(ctx->db_count, cnt.data(), sizeof(unsigned long long) * n, hipMemcpyHostToDevice, ctx->stream));

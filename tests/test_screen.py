@@ -198,12 +198,18 @@ def test_screened_database_rows(engine):
     a = engine.nsqMain(**kw); ra = engine.db_export(); engine.db_reset()
     b = engine.nsqMain(mpopt=api.mpoption(screen=1), **kw); rb = engine.db_export(); engine.db_reset()
     assert a.database_row_count == b.database_row_count
-    for k in ("states", "count", "dns", "flag", "nodal", "status", "relaxed"):
+    for k in ("states", "count", "dns", "flag", "nodal", "status"):
         assert np.array_equal(ra[k], rb[k]), k
+    assert np.array_equal(ra["relaxed"], rb["relaxed"] & 1) and not (ra["relaxed"] & 2).any()          # bit 1 of the exported column: certified, never solved
     assert np.array_equal(_split(a.acc)[0], _split(b.acc)[0])
     np.testing.assert_allclose(_split(b.acc)[3], _split(a.acc)[3], rtol=1e-13)
-    skipped = rb["iters"] == 0
-    assert np.all(rb["dns"][skipped & (rb["status"] == 0)] == 0) and b.n_screened == int(rb["count"][skipped & (rb["status"] == 0)].sum())
+    skipped = (rb["relaxed"] & 2) != 0
+    assert np.array_equal(skipped, (rb["iters"] == 0) & (rb["status"] == 0)) and np.all(rb["dns"][skipped] == 0) and b.n_screened == int(rb["count"][skipped].sum())
+    # export -> import -> export keeps the bit, and with it n_screened of the resumed database
+    engine.nsqMain(mpopt=api.mpoption(screen=1), **kw); rows = engine.db_export(); engine.db_reset()
+    engine.db_import(rows, mpopt=api.mpoption(screen=1))
+    assert engine.db_accumulate().n_screened == b.n_screened and np.array_equal(engine.db_export()["relaxed"], rows["relaxed"])
+    engine.db_reset()
     assert 0.5 < skipped.mean() < 0.8 and np.array_equal(ra["iters"][~skipped], rb["iters"][~skipped])
     assert b.n_screened > 0.88 * b.current_iteration and a.n_screened == 0
     # a database filled without the pre-screen refuses a batch with it (results of other solver options)
