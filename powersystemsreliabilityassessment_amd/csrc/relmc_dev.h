@@ -175,7 +175,7 @@ struct ScreenTab {
     const double* f_min;            // [nl] MW flow of (all units at Pmin) through the PTDF
     const double* f_rng;            // [nl] MW flow of (all units' ranges)
     const double* f_load;           // [nl] MW flow of the bus loads at scale 1 (positive = the loads' own contribution, subtracted)
-    const double* lim;              // [nl] MW rating shrunk by the safety margin; +inf = no limit
+    const double* lim;              // [nl] MW rating + 1e-9 MW of rounding slack; +inf = no limit
     const double* gpair;            // [nl][ng][2] {PTDF[l, bus(k)] * Pmin_k, PTDF[l, bus(k)] * (Pmax_k - Pmin_k)}, 16-byte aligned pairs
     const double* lodf;             // [nl (line out m)][nl] flow change on l per MW of pre-outage flow on m; lodf[m][m] = -1
     const uint8_t* bridge;          // [nl] 1 = taking the line out splits the network: never certified

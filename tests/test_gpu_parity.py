@@ -686,11 +686,11 @@ def test_full_size_properties_1e8_eight_shards(engine):
     mi, md = merged.to_arrays(); di, dd = db.acc.to_arrays()
     assert np.array_equal(mi, di) and merged.n == n and merged.n_nonconverged == 0
     np.testing.assert_allclose(md, dd, rtol=1e-12, atol=1e-6)
-    # ... and a third route (round 6): the same 1e8 samples behind the zero-curtailment pre-screen -- 9.03e7 of them counted without being solved --
+    # ... and a third route (round 6): the same 1e8 samples behind the zero-curtailment pre-screen -- 9.14e7 of them counted without being solved --
     # give the same integers but the iteration sum, and the same sums to their order
     scr = engine.nsq_accumulate(seed, 0, n, api.mpoption(screen=1))
     si, sd = scr.to_arrays()
-    assert np.array_equal(si[:5], mi[:5]) and np.array_equal(si[6:-1], mi[6:-1]) and 0.90 * n < scr.n_screened < 0.91 * n and merged.n_screened == 0
+    assert np.array_equal(si[:5], mi[:5]) and np.array_equal(si[6:-1], mi[6:-1]) and 0.91 * n < scr.n_screened < 0.92 * n and merged.n_screened == 0
     np.testing.assert_allclose(sd, md, rtol=1e-12, atol=1e-6)
     ix = dist.indices_from_acc(merged, engine.case.nb, engine.case.ncomp)
     assert 0.00044 < ix["beta"] < 0.00048 and abs(ix["edns"] - 15.197) < 0.02 and abs(ix["plc"] - 0.084969) < 1e-4

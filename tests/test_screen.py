@@ -59,8 +59,8 @@ def test_model_certificate_is_sound_on_rts24(case, oracle, model, states_fixture
     assert not np.any(cert & (d["dns"] != 0)) and not np.any(cert & (d["status"] != 0)) and not np.any(cert & (d["relaxed"] != 0))
     share, of_zero = c[cert].sum() / c.sum(), c[cert].sum() / c[d["dns"] == 0].sum()
     print(f"\nRTS-24 certificate: {share:.4f} of 4e5 samples, {of_zero:.4f} of the zero-curtailment ones")
-    assert 0.89 < share < 0.92 and of_zero > 0.98
-    # base topology only (what VERDICT r5 probed): 85 %
+    assert 0.905 < share < 0.92 and of_zero > 0.995
+    # base topology only (what VERDICT r5 probed at 85 %; 86.5 % with flows allowed ON their rating)
     base = model.certify(case, ptdf, lodf, d["states"], max_lines_out=0)
     assert 0.84 < c[base].sum() / c.sum() < 0.87 and not np.any(base & ~cert)
 
@@ -130,7 +130,7 @@ def test_screened_accumulate_equals_unscreened_rts24_2e6(engine, policy, capsys)
     a = engine.nsq_accumulate(3, 10**9, n, api.mpoption(policy)); ta = engine.last_kernel_ms()
     b = engine.nsq_accumulate(3, 10**9, n, api.mpoption(policy, screen=1)); tb = engine.last_kernel_ms()
     ia, ita, sa, da = _split(a); ib, itb, sb, db = _split(b)
-    assert np.array_equal(ia, ib) and sa == 0 and 0.89 * n < sb < 0.92 * n and itb < 0.15 * ita
+    assert np.array_equal(ia, ib) and sa == 0 and 0.905 * n < sb < 0.92 * n and itb < 0.13 * ita
     np.testing.assert_allclose(db, da, rtol=1e-13, atol=0)
     assert a.n == b.n == n and a.n_nonconverged == b.n_nonconverged == 0
     with capsys.disabled():

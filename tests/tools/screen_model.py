@@ -40,7 +40,7 @@ def tables(case):
     return ptdf, lodf
 
 
-def certify(case, ptdf, lodf, states, load_scale=1.0, margin=1e-9, max_lines_out=1, variant="prop"):
+def certify(case, ptdf, lodf, states, load_scale=1.0, slack_mw=1e-9, max_lines_out=1, variant="prop"):
     """certified[n] (bool) for states[n, ncomp] (1 = failed)."""
     st = np.asarray(states, dtype=bool)
     n = st.shape[0]
@@ -67,7 +67,9 @@ def certify(case, ptdf, lodf, states, load_scale=1.0, margin=1e-9, max_lines_out
         Fm = F[one, m]
         F[one] = np.where(bridge[:, None], np.inf, F[one] + np.nan_to_num(col) * Fm[:, None])
     lim = np.where(case.br_rate > 0, case.br_rate, np.inf)[None, :]
-    ok &= np.all(np.abs(F) <= lim * (1.0 - margin), axis=1)
+    # a flow may sit ON its rating (RTS-24: the capacity in service equals the load in 1 % of the samples, every unit then runs at Pmax and the bridge to bus 7
+    # carries exactly its 175 MW): 1e-9 MW of slack for the rounding of the PTDF sums, four orders inside the 5e-6 p.u. MIPS itself accepts as feasible (feastol)
+    ok &= np.all(np.abs(F) <= lim + slack_mw, axis=1)
     return ok
 
 
