@@ -237,15 +237,13 @@ bool invert(std::vector<double>& A, int n)
 }
 }  // namespace
 
-// relmc_case_load: PTDF / LODF tables of the certificate, host arithmetic, one device buffer.  A case the certificate cannot describe (the base
-// topology is not one island, no unit has a range) gets valid = 0: screen = 1 then certifies nothing.
-int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
+// The certificate's tables as host arrays (pure arithmetic: no device, no context -- relmc_debug_screen_tables hands them to the CPU test suite).
+// Layout of h: pmin[ng], rng[ng], f_min[nl], f_rng[nl], f_load[nl], lim[nl], gpair[nl][ng][2], lodf[nl][nl]; bridge[nl].  false = a case the certificate
+// cannot describe (the base topology is not one island, no unit has a range, a malformed branch).
+bool screen_tables(const relmc_case_desc* d, std::vector<double>& h, std::vector<uint8_t>& bridge, double* sum_pmin_out, double* sum_rng_out)
 {
-    screen_free(ctx);                                        // the work buffers are sized for the tile of the case that was loaded
-    auto& S = ctx->screen;
     const int nb = d->nb, ng = d->ng, nl = d->nl;
-    S.tab.nl = nl; S.tab.ng = ng; S.tab.valid = 0; S.tab.total_load = d->total_load;
-    if (nl < 1 || ng < 1 || nb < 2) return RELMC_OK;
+    if (nl < 1 || ng < 1 || nb < 2) return false;
     std::vector<double> X((size_t)nb * nb, 0.0);             // X[i][j], reference row / column zero
     {
         const int n = nb - 1;
@@ -253,28 +251,28 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
         std::vector<double> B((size_t)n * n, 0.0);
         for (int l = 0; l < nl; ++l) {
             const int f = d->br_from[l], t = d->br_to[l]; const double b = d->br_b[l];
-            if (f < 0 || f >= nb || t < 0 || t >= nb || f == t) return RELMC_OK;
+            if (f < 0 || f >= nb || t < 0 || t >= nb || f == t) return false;
             if (f != d->ref_bus) B[(size_t)red(f) * n + red(f)] += b;
             if (t != d->ref_bus) B[(size_t)red(t) * n + red(t)] += b;
             if (f != d->ref_bus && t != d->ref_bus) { B[(size_t)red(f) * n + red(t)] -= b; B[(size_t)red(t) * n + red(f)] -= b; }
         }
-        if (!invert(B, n)) return RELMC_OK;
+        if (!invert(B, n)) return false;
         for (int i = 0; i < nb; ++i) for (int j = 0; j < nb; ++j)
             if (i != d->ref_bus && j != d->ref_bus) X[(size_t)i * nb + j] = B[(size_t)red(i) * n + red(j)];
     }
     auto ptdf = [&](int l, int bus) { return d->br_b[l] * (X[(size_t)d->br_from[l] * nb + bus] - X[(size_t)d->br_to[l] * nb + bus]); };
     const size_t n_d = (size_t)2 * ng + (size_t)4 * nl + (size_t)2 * nl * ng + (size_t)nl * nl;       // the pair table starts 16-byte aligned (2 ng + 4 nl doubles before it)
-    std::vector<double> h(n_d, 0.0);
+    h.assign(n_d, 0.0);
     double* pmin = h.data(); double* rng = pmin + ng; double* f_min = rng + ng; double* f_rng = f_min + nl; double* f_load = f_rng + nl; double* lim = f_load + nl;
     double* gpair = lim + nl; double* lodf = gpair + (size_t)2 * nl * ng;
-    std::vector<uint8_t> bridge((size_t)nl, 0);
+    bridge.assign((size_t)nl, 0);
     double sum_pmin = 0.0, sum_rng = 0.0;
     for (int k = 0; k < ng; ++k) {
         pmin[k] = d->inj_pmin[k]; rng[k] = d->inj_pmax[k] - d->inj_pmin[k];
-        if (!(rng[k] >= 0.0)) return RELMC_OK;
+        if (!(rng[k] >= 0.0) || d->inj_bus[k] < 0 || d->inj_bus[k] >= nb) return false;
         sum_pmin += pmin[k]; sum_rng += rng[k];
     }
-    if (!(sum_rng > 0.0)) return RELMC_OK;
+    if (!(sum_rng > 0.0)) return false;
     // A flow may sit ON its rating (RTS-24: the capacity in service equals the load in 1 % of the samples; every unit then runs at Pmax and the bridge to
     // bus 7 carries exactly its 175 MW): 1e-9 MW of slack for the rounding of the PTDF sums -- four orders inside the 5e-6 p.u. MIPS accepts as feasible.
     constexpr double kSlackMW = 1e-9;
@@ -296,6 +294,22 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
         for (int l = 0; l < nl; ++l) lodf[(size_t)m * nl + l] = (ptdf(l, fm) - ptdf(l, tm)) / den;
         lodf[(size_t)m * nl + m] = -1.0;
     }
+    *sum_pmin_out = sum_pmin; *sum_rng_out = sum_rng;
+    return true;
+}
+
+// relmc_case_load: PTDF / LODF tables of the certificate into one device buffer.  A case the certificate cannot describe gets valid = 0:
+// screen = 1 then certifies nothing.
+int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
+{
+    screen_free(ctx);                                        // the work buffers are sized for the tile of the case that was loaded
+    auto& S = ctx->screen;
+    const int ng = d->ng, nl = d->nl;
+    S.tab.nl = nl; S.tab.ng = ng; S.tab.valid = 0; S.tab.total_load = d->total_load;
+    std::vector<double> h; std::vector<uint8_t> bridge;
+    double sum_pmin = 0.0, sum_rng = 0.0;
+    if (!screen_tables(d, h, bridge, &sum_pmin, &sum_rng)) return RELMC_OK;
+    const size_t n_d = h.size();
     HIP_TRY(ctx, hipSetDevice(ctx->device));
     const size_t bytes = n_d * sizeof(double) + (size_t)nl;
     HIP_TRY(ctx, hipMalloc(&S.dtab, bytes));
@@ -412,6 +426,20 @@ int screen_seq_compact(relmc_ctx* ctx, const uint32_t* masks, int n_years, uint1
 using namespace relmc_host;
 
 extern "C" {
+
+// Host-only introspection (no device, no context; not part of include/relmc.h): the certificate's tables as relmc_case_load builds them, for the CPU test
+// suite to hold against numpy's PTDF / LODF.  out_doubles[2 ng + 4 nl + 2 nl ng + nl nl] in the layout of screen_tables, bridge_out[nl], sums_out[2] =
+// {sum Pmin, sum range}.  Returns 1 = tables built, 0 = the case has no certificate, < 0 = bad arguments.
+int32_t relmc_debug_screen_tables(const relmc_case_desc* d, double* out_doubles, int64_t cap, uint8_t* bridge_out, double* sums_out)
+{
+    if (!d || !out_doubles || !bridge_out || !sums_out) return RELMC_ERR_INVALID;
+    std::vector<double> h; std::vector<uint8_t> bridge;
+    if (!screen_tables(d, h, bridge, &sums_out[0], &sums_out[1])) return 0;
+    if ((int64_t)h.size() > cap) return RELMC_ERR_INVALID;
+    std::memcpy(out_doubles, h.data(), sizeof(double) * h.size());
+    std::memcpy(bridge_out, bridge.data(), bridge.size());
+    return 1;
+}
 
 // Test hook (not part of include/relmc.h): the device's certificate for given states.  states_host [n][ncomp] (1 = failed), load_scale_host optional
 // [n] (the sequential track's hourly factor; null = 1) -> certified_host[n] (1 = the pre-screen would skip this state).
