@@ -165,7 +165,8 @@ struct EvalArgs {
 
 // Zero-curtailment certificate (relmc_screen.hip; SURVEY 8f rank 4, mc_simulation.m:57-59, 65): tables built by relmc_case_load on the host, resident in
 // HBM, read through the vector-memory path.  A state is certified when the units in service, loaded proportionally between Pmin and Pmax,
-// serve the whole load with every DC flow inside its rating: base-topology PTDF, one line out through its LODF column, more lines out never.
+// serve the whole load with every DC flow inside (or on) its rating: base-topology PTDF, one or two lines out through the outage system
+// (I - H_MM) x = F_M, more lines out never.
 struct ScreenTab {
     int32_t nl, ng, valid, pad;
     double total_load;              // MW at load scale 1
@@ -177,8 +178,8 @@ struct ScreenTab {
     const double* f_load;           // [nl] MW flow of the bus loads at scale 1 (positive = the loads' own contribution, subtracted)
     const double* lim;              // [nl] MW rating + 1e-9 MW of rounding slack; +inf = no limit
     const double* gpair;            // [nl][ng][2] {PTDF[l, bus(k)] * Pmin_k, PTDF[l, bus(k)] * (Pmax_k - Pmin_k)}, 16-byte aligned pairs
-    const double* lodf;             // [nl (line out m)][nl] flow change on l per MW of pre-outage flow on m; lodf[m][m] = -1
-    const uint8_t* bridge;          // [nl] 1 = taking the line out splits the network: never certified
+    const double* hmat;             // [nl (line out m)][nl] H[m][l]: flow on l per MW sent from from(m) to to(m) in the base topology (the outage formulas' matrix)
+    const uint8_t* bridge;          // [nl] 1 = taking the line out splits the network (1 - H[m][m] = 0; the certificate tests that itself)
 };
 
 // device image of relmc_acc (include/relmc.h): 6 + 256 + 1 int64, then 2 + 128 doubles

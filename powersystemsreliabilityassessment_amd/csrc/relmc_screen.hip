@@ -5,7 +5,8 @@
 // zero curtailment the reference's outputs are exactly (0, zeros(1, nb)) whatever MIPS' trajectory was.  An explicit dispatch that serves all load
 // inside every unit and line limit PROVES that optimum.  The certificate tried here (tests/tools/screen_model.py is its host model, 0 false
 // certificates against the oracle): units in service loaded proportionally between Pmin and Pmax, DC flows through the base-topology PTDF --
-// states with one line out through that line's LODF column, states with more lines out (or a bridge out) never -- inside (or on) every rating.
+// states with one or two lines out through the outage system (I - H_MM) x = F_M, states with more lines out (or an outage that splits the network) never --
+// inside (or on) every rating.
 // It covers 91.4 % of the RTS-24 samples (99.9 % of the zero-curtailment ones), 97.0 % of RTS-96's, 99.2 % of the sequential
 // track's contingency hours; everything else goes through the interior point as before.
 //
@@ -32,7 +33,7 @@ DEVFI bool screen_certify(const ScreenTab& T, const uint32_t (&m)[OW], double sc
 {
     const int ng = T.ng, nl = T.nl;
     double lo = T.sum_pmin, rg = T.sum_rng;
-    int nlo = 0, mline = 0, nout = 0;
+    int nlo = 0, m1 = 0, m2 = 0, nout = 0;
     // the units out of service, one byte each (at most 16: a state with more goes to the interior point), so that the loop over the lines below
     // walks a short list instead of scanning the mask words again for every line
     unsigned long long list0 = 0ull, list1 = 0ull;
@@ -46,13 +47,12 @@ DEVFI bool screen_certify(const ScreenTab& T, const uint32_t (&m)[OW], double sc
                 lo -= T.pmin[k]; rg -= T.rng[k];
                 if (nout < 8) list0 |= (unsigned long long)k << (8 * nout); else if (nout < 16) list1 |= (unsigned long long)k << (8 * (nout - 8));
                 nout += 1;
-            } else { nlo += 1; mline = k - ng; }
+            } else { if (nlo == 0) m1 = k - ng; else m2 = k - ng; nlo += 1; }
         }
     }
-    if (nlo > 1 || nout > 16) return false;                     // two or more lines out (or an improbable number of units): the interior point
+    if (nlo > 2 || nout > 16) return false;                     // three or more lines out (or an improbable number of units): the interior point
     const double L = T.total_load * scale;
     if (!(lo <= L) || !(L <= lo + rg) || !(rg > 0.0)) return false;   // capacity short of the load, or over-generation at Pmin
-    if (nlo == 1 && T.bridge[mline]) return false;
     const double t = (L - lo) / rg;                              // every unit in service at Pmin + t (Pmax - Pmin), 0 <= t <= 1
     auto flow = [&](int l) -> double {
         double a = T.f_min[l], b = T.f_rng[l];
@@ -64,12 +64,28 @@ DEVFI bool screen_certify(const ScreenTab& T, const uint32_t (&m)[OW], double sc
         }
         return __builtin_fma(t, b, a) - scale * T.f_load[l];
     };
-    double fm = 0.0;
-    const double* lod = T.lodf + (size_t)mline * nl;
-    if (nlo == 1) fm = flow(mline);
+    // Lines out: transfers x on their terminals with (I - H_MM) x = F_M cancel what would flow through them; F' = F + H[:, M] x (H[m][l] = flow on l per unit
+    // sent from from(m) to to(m) in the base topology).  One line: x = F_m / (1 - H_mm).  Two: the 2 x 2 system.  A singular system = the outage splits the
+    // network (a bridge; a pair that is a cut): never certified.
+    double x1 = 0.0, x2 = 0.0;
+    const double* h1 = T.hmat + (size_t)m1 * nl;
+    const double* h2 = T.hmat + (size_t)m2 * nl;
+    if (nlo == 1) {
+        const double den = 1.0 - h1[m1];
+        if (!(__builtin_fabs(den) >= 1e-8)) return false;
+        x1 = flow(m1) / den;
+    } else if (nlo == 2) {
+        const double a11 = 1.0 - h1[m1], a12 = -h2[m1], a21 = -h1[m2], a22 = 1.0 - h2[m2];      // row of line m1: (1 - H[m1][m1]) x1 - H[m1][m2] x2 = F_m1, with H[l][m] = hmat[m][l]
+        const double det = a11 * a22 - a12 * a21;
+        if (!(__builtin_fabs(det) >= 1e-8)) return false;
+        const double F1 = flow(m1), F2 = flow(m2);
+        x1 = (a22 * F1 - a12 * F2) / det; x2 = (a11 * F2 - a21 * F1) / det;
+    }
     for (int l = 0; l < nl; ++l) {
+        if (nlo >= 1 && (l == m1 || (nlo == 2 && l == m2))) continue;      // a line out carries nothing
         double f = flow(l);
-        if (nlo == 1) f = __builtin_fma(lod[l], fm, f);        // lodf[m][m] = -1: the line out carries nothing
+        if (nlo >= 1) f = __builtin_fma(h1[l], x1, f);
+        if (nlo == 2) f = __builtin_fma(h2[l], x2, f);
         if (!(__builtin_fabs(f) <= T.lim[l])) return false;
     }
     return true;
@@ -238,7 +254,7 @@ bool invert(std::vector<double>& A, int n)
 }  // namespace
 
 // The certificate's tables as host arrays (pure arithmetic: no device, no context -- relmc_debug_screen_tables hands them to the CPU test suite).
-// Layout of h: pmin[ng], rng[ng], f_min[nl], f_rng[nl], f_load[nl], lim[nl], gpair[nl][ng][2], lodf[nl][nl]; bridge[nl].  false = a case the certificate
+// Layout of h: pmin[ng], rng[ng], f_min[nl], f_rng[nl], f_load[nl], lim[nl], gpair[nl][ng][2], hmat[nl (line out m)][nl]; bridge[nl] (1 - H[m][m] = 0).  false = a case the certificate
 // cannot describe (the base topology is not one island, no unit has a range, a malformed branch).
 bool screen_tables(const relmc_case_desc* d, std::vector<double>& h, std::vector<uint8_t>& bridge, double* sum_pmin_out, double* sum_rng_out)
 {
@@ -264,7 +280,7 @@ bool screen_tables(const relmc_case_desc* d, std::vector<double>& h, std::vector
     const size_t n_d = (size_t)2 * ng + (size_t)4 * nl + (size_t)2 * nl * ng + (size_t)nl * nl;       // the pair table starts 16-byte aligned (2 ng + 4 nl doubles before it)
     h.assign(n_d, 0.0);
     double* pmin = h.data(); double* rng = pmin + ng; double* f_min = rng + ng; double* f_rng = f_min + nl; double* f_load = f_rng + nl; double* lim = f_load + nl;
-    double* gpair = lim + nl; double* lodf = gpair + (size_t)2 * nl * ng;
+    double* gpair = lim + nl; double* hmat = gpair + (size_t)2 * nl * ng;
     bridge.assign((size_t)nl, 0);
     double sum_pmin = 0.0, sum_rng = 0.0;
     for (int k = 0; k < ng; ++k) {
@@ -287,12 +303,10 @@ bool screen_tables(const relmc_case_desc* d, std::vector<double>& h, std::vector
         f_min[l] = a; f_rng[l] = b; f_load[l] = c;
         lim[l] = d->br_rate[l] > 0.0 ? d->br_rate[l] + kSlackMW : std::numeric_limits<double>::infinity();
     }
-    for (int m = 0; m < nl; ++m) {
+    for (int m = 0; m < nl; ++m) {                            // H[m][l]: flow on l per unit sent from from(m) to to(m); a bridge has H[m][m] = 1
         const int fm = d->br_from[m], tm = d->br_to[m];
-        const double den = 1.0 - (ptdf(m, fm) - ptdf(m, tm));
-        if (std::fabs(den) < 1e-8) { bridge[(size_t)m] = 1; continue; }
-        for (int l = 0; l < nl; ++l) lodf[(size_t)m * nl + l] = (ptdf(l, fm) - ptdf(l, tm)) / den;
-        lodf[(size_t)m * nl + m] = -1.0;
+        for (int l = 0; l < nl; ++l) hmat[(size_t)m * nl + l] = ptdf(l, fm) - ptdf(l, tm);
+        if (std::fabs(1.0 - hmat[(size_t)m * nl + m]) < 1e-8) bridge[(size_t)m] = 1;
     }
     *sum_pmin_out = sum_pmin; *sum_rng_out = sum_rng;
     return true;
@@ -318,7 +332,7 @@ int screen_build(relmc_ctx* ctx, const relmc_case_desc* d)
     const double* dd = reinterpret_cast<const double*>(S.dtab);
     S.tab.sum_pmin = sum_pmin; S.tab.sum_rng = sum_rng;
     S.tab.pmin = dd; S.tab.rng = dd + ng; S.tab.f_min = dd + 2 * ng; S.tab.f_rng = S.tab.f_min + nl; S.tab.f_load = S.tab.f_rng + nl; S.tab.lim = S.tab.f_load + nl;
-    S.tab.gpair = S.tab.lim + nl; S.tab.lodf = S.tab.gpair + (size_t)2 * nl * ng;
+    S.tab.gpair = S.tab.lim + nl; S.tab.hmat = S.tab.gpair + (size_t)2 * nl * ng;
     S.tab.bridge = reinterpret_cast<const uint8_t*>(dd + n_d);
     S.tab.valid = 1;
     return RELMC_OK;

@@ -520,7 +520,7 @@ def test_bench_comm_paths_are_self_evidencing(tmp_path):
     # ... and the same workloads behind the zero-curtailment pre-screen (relmc_solver_opts.screen), beside the headline, never as `value`
     scr = j1["screened"]
     assert {"nsq24", "rts96", "seq", "time_to_cov_1pct", "distinct_state_path"} <= set(scr)
-    assert 0.88 < scr["nsq24"]["n_screened_frac"] < 0.93 and 0.95 < scr["rts96"]["n_screened_frac"] < 0.99 and scr["seq"]["n_screened_frac"] > 0.98
+    assert 0.88 < scr["nsq24"]["n_screened_frac"] < 0.93 and 0.96 < scr["rts96"]["n_screened_frac"] < 0.995 and scr["seq"]["n_screened_frac"] > 0.98
     assert scr["nsq24"]["value"] > 2.0 * j1["value"] and scr["rts96"]["value"] > 2.0 * sec["rts96"]["value"] and scr["seq"]["value"] > 2.0 * sec["seq"]["value"]
     assert scr["time_to_cov_1pct"]["samples"] == 211_200 and all(scr[k]["n_nonconverged"] == 0 for k in ("nsq24", "rts96", "seq"))
     assert sec["seq"]["n_nonconverged"] == 0 and sec["seq"]["years_per_s"] > 100 and sec["hl1"]["lole_h_per_yr"] == pytest.approx(9.39, rel=0.05)

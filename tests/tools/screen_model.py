@@ -22,15 +22,8 @@ sys.path.insert(0, ROOT)
 
 def tables(case):
     """PTDF [nl, nb] (reference bus column = 0), LODF [nl, nl] (column m: flow change per unit pre-outage flow of line m; NaN column = bridge)."""
-    nb, nl = case.nb, case.nl
-    f, t, b = case.br_from, case.br_to, case.br_b
-    Bf = np.zeros((nl, nb)); Bf[np.arange(nl), f] = b; Bf[np.arange(nl), t] = -b
-    A = np.zeros((nl, nb)); A[np.arange(nl), f] = 1.0; A[np.arange(nl), t] = -1.0
-    Bbus = A.T @ Bf
-    keep = np.arange(nb) != case.ref_bus
-    X = np.zeros((nb, nb)); X[np.ix_(keep, keep)] = np.linalg.inv(Bbus[np.ix_(keep, keep)])
-    ptdf = Bf @ X
-    H = ptdf @ A.T                                   # H[l, m] = flow on l per unit injected at from(m), withdrawn at to(m)
+    ptdf, H = ptdf_h(case)
+    nl = case.nl
     lodf = np.full((nl, nl), np.nan)
     for m in range(nl):
         den = 1.0 - H[m, m]
@@ -40,7 +33,20 @@ def tables(case):
     return ptdf, lodf
 
 
-def certify(case, ptdf, lodf, states, load_scale=1.0, slack_mw=1e-9, max_lines_out=1, variant="prop"):
+def ptdf_h(case):
+    """PTDF [nl, nb] and H [nl, nl]: H[l, m] = flow on l per unit injected at from(m) and withdrawn at to(m) (what the outage formulas are made of)."""
+    nb, nl = case.nb, case.nl
+    f, t, b = case.br_from, case.br_to, case.br_b
+    Bf = np.zeros((nl, nb)); Bf[np.arange(nl), f] = b; Bf[np.arange(nl), t] = -b
+    A = np.zeros((nl, nb)); A[np.arange(nl), f] = 1.0; A[np.arange(nl), t] = -1.0
+    Bbus = A.T @ Bf
+    keep = np.arange(nb) != case.ref_bus
+    X = np.zeros((nb, nb)); X[np.ix_(keep, keep)] = np.linalg.inv(Bbus[np.ix_(keep, keep)])
+    ptdf = Bf @ X
+    return ptdf, ptdf @ A.T
+
+
+def certify(case, ptdf, lodf, states, load_scale=1.0, slack_mw=1e-9, max_lines_out=2, variant="prop"):
     """certified[n] (bool) for states[n, ncomp] (1 = failed)."""
     st = np.asarray(states, dtype=bool)
     n = st.shape[0]
@@ -66,6 +72,24 @@ def certify(case, ptdf, lodf, states, load_scale=1.0, slack_mw=1e-9, max_lines_o
         bridge = np.isnan(col[:, 0])
         Fm = F[one, m]
         F[one] = np.where(bridge[:, None], np.inf, F[one] + np.nan_to_num(col) * Fm[:, None])
+    two = np.flatnonzero(ok & (nout == 2))
+    if two.size:
+        # two lines out: transfers x on their terminals with (I - H_MM) x = F_M cancel what would flow through them; F' = F + H[:, M] x, F'_M = 0.
+        # A singular 2 x 2 system = the pair splits the network: never certified
+        H = getattr(case, "_screen_H", None)
+        if H is None:
+            H = ptdf_h(case)[1]; object.__setattr__(case, "_screen_H", H)
+        idx = np.argsort(~lout[two], axis=1, kind="stable")[:, :2]     # the two outaged lines, ascending
+        m1, m2 = idx[:, 0], idx[:, 1]
+        a11, a12, a21, a22 = 1.0 - H[m1, m1], -H[m1, m2], -H[m2, m1], 1.0 - H[m2, m2]
+        det = a11 * a22 - a12 * a21
+        split = np.abs(det) < 1e-8
+        dets = np.where(split, 1.0, det)
+        F1, F2 = F[two, m1], F[two, m2]
+        x1 = (a22 * F1 - a12 * F2) / dets; x2 = (a11 * F2 - a21 * F1) / dets
+        Fn = F[two] + H[:, m1].T * x1[:, None] + H[:, m2].T * x2[:, None]
+        Fn[np.arange(two.size), m1] = 0.0; Fn[np.arange(two.size), m2] = 0.0
+        F[two] = np.where(split[:, None], np.inf, Fn)
     lim = np.where(case.br_rate > 0, case.br_rate, np.inf)[None, :]
     # a flow may sit ON its rating (RTS-24: the capacity in service equals the load in 1 % of the samples, every unit then runs at Pmax and the bridge to bus 7
     # carries exactly its 175 MW): 1e-9 MW of slack for the rounding of the PTDF sums, four orders inside the 5e-6 p.u. MIPS itself accepts as feasible (feastol)
@@ -82,18 +106,18 @@ def seq_model(n_years):
     orc = coracle.Oracle(case)
     rel = seq.seqmeantime(); lf = loadcurve.anloducurve(8736)[2]
     tot = cont = cert_n = zero_n = false_n = 0
-    cert_by = {0: 0, 1: 0}
+    cert_by = {0: 0, 1: 0, 2: 0}
     for y in range(n_years):
         st = orc.seq_mcsampling(rel, 8736, 1, y, 1)
         hrs = np.flatnonzero(st.any(1))
         r = orc.seq_mcsimulation(st[hrs], lf[hrs], nthreads=16)
-        for mlo in (0, 1):
+        for mlo in (0, 1, 2):
             c = certify(case, ptdf, lodf, st[hrs], load_scale=lf[hrs], max_lines_out=mlo)
             cert_by[mlo] += int(c.sum())
         false_n += int((c & (r["dns"] != 0)).sum())
         tot += 8736; cont += hrs.size; zero_n += int((r["dns"] == 0).sum())
     print(f"seq: {n_years} years, contingency hours {cont} of {tot} ({cont / tot:.4f}); zero-dns share of them {zero_n / cont:.5f}")
-    for mlo in (0, 1):
+    for mlo in (0, 1, 2):
         print(f"  proportional, <= {mlo} lines out: certified {cert_by[mlo] / cont:.5f} of the contingency hours")
     print(f"  FALSE certificates {false_n}")
 
@@ -114,7 +138,7 @@ def main():
     print(f"{what}: {int(N)} samples, {len(c)} distinct states, oracle {time.time() - t0:.1f} s; zero-dns share {c[d['dns'] == 0].sum() / N:.4f}")
     nout = d["states"][:, case.ng:].sum(1)
     print("  lines out 0/1/2+: %.4f %.4f %.4f" % tuple(c[m].sum() / N for m in (nout == 0, nout == 1, nout >= 2)))
-    for mlo in (0, 1):
+    for mlo in (0, 1, 2):
         cert = certify(case, ptdf, lodf, d["states"], max_lines_out=mlo)
         false = cert & (d["dns"] != 0)
         print(f"  proportional, <= {mlo} lines out: certified {c[cert].sum() / N:.4f} of samples ({cert.sum()} states), "
