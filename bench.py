@@ -640,8 +640,8 @@ def screened_rates(eng24, device, policy, seed, B, steps=3):
                 "solved_per_step": (n - ns) / len(accs), "mean_ipm_iterations_of_the_solved": sum(int(a.sum_iters) for a in accs) / max(1, n - ns),
                 "n_nonconverged": sum(int(a.n_nonconverged) for a in accs)}
 
-    res = {"what": "relmc_solver_opts.screen = 1: zero-curtailment certificate (proportional dispatch of the units in service through the base-topology PTDF, one line out "
-                   "through its LODF column) in a pre-pass, one thread per sample; only the uncovered samples reach the interior point.  Outputs other than the iteration "
+    res = {"what": "relmc_solver_opts.screen = 1: zero-curtailment certificate (proportional dispatch of the units in service through the base-topology PTDF, one or two lines out "
+                   "through the outage system) in a pre-pass, one thread per sample; only the uncovered samples reach the interior point.  Outputs other than the iteration "
                    "statistics are those of the unscreened run (tests/test_screen.py); `value` above stays every-sample-solved"}
     accs, dt, kms = timed(lambda k: eng24.nsq_accumulate(seed, (1 << 41) + k * B, B, so), eng24)
     res["nsq24"] = line(accs, dt, kms, B, "scenarios/s", f"HL2 non-sequential MCS, IEEE RTS-24, {B} samples per step (BASELINE configs[1]) behind the pre-screen")

@@ -101,7 +101,7 @@ typedef struct {
     double max_stepsize;      /* 1e10 */
     int32_t screen;           /* 0 (default): every unit goes through the interior point.  1: zero-curtailment pre-screen: a unit
                                  for which an explicit dispatch serves all load -- units in service loaded proportionally between Pmin and Pmax, DC
-                                 flows through the base-topology PTDF (one line out: + its LODF column) inside or on every rating -- has LP optimum 0, so the
+                                 flows through the base-topology PTDF (one or two lines out: + the outage system's corrections) inside or on every rating -- has LP optimum 0, so the
                                  reference's outputs for it are exactly (0, zeros) (mc_simulation.m:57-59, 65) and it is counted without being solved.
                                  Every output but the iteration statistics is the one of screen = 0 (of its converged solves: a unit the interior point
                                  would have left non-converged is counted with the proven optimum); relmc_acc.n_screened counts the skipped units.
