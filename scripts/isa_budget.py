@@ -88,8 +88,7 @@ def build_cfg(body):
     for ln in body:
         m = re.match(r"^(\.LBB\d+_\d+):", ln)
         if m:
-            if cur.ins or cur.label != "<entry>" or True:
-                nb = Block(len(blocks), m.group(1)); blocks.append(nb); cur = nb
+            nb = Block(len(blocks), m.group(1)); blocks.append(nb); cur = nb
             continue
         s = ln.strip()
         if not s or s.startswith((";", ".", "//")):
@@ -207,7 +206,6 @@ def loop_forest(blocks, reach):
 def main():
     args = [a for a in sys.argv[1:] if not a.startswith("--") and a.isdigit()]
     tile = int(args[0]) if args else 24
-    tree = False
     # launch geometry and iteration statistics of the 1e6-scenario launch the counters were taken on (bench.py's step)
     P = dict(n=1_000_000, waves=256 * 2 * 4 if tile == 24 else 256 * 8, rows=4 if tile == 24 else 1, rw=16 if tile == 24 else 64)
     if "--params" in sys.argv: P.update(json.loads(sys.argv[sys.argv.index("--params") + 1]))
@@ -234,9 +232,6 @@ def main():
                        rfl=sum(o.startswith("v_readfirstlane") for o in own_ops), ds=sum(o.startswith("ds_") for o in own_ops),
                        setprio=sum(o.startswith("s_setprio") for o in own_ops), rcp=sum(o.startswith("v_rcp_f64") for o in own_ops),
                        philox=sum(o.startswith(("v_mad_u64_u32", "v_mul_hi_u32")) for o in own_ops))
-    if tree:
-        for h in sorted(hdrs, key=lambda h: min(loops[h])):
-            print("  " * depth[h] + f"loop @{blocks[h].label} blocks {len(loops[h])} ins {feat[h]['n']} own {feat[h]['own']} {feat[h]}")
 
     # ---- what each loop is, and how often it runs ------------------------------------------------------------------------------------------
     sys.path.insert(0, os.path.join(ROOT, "tests")); sys.path.insert(0, ROOT)
@@ -251,7 +246,6 @@ def main():
         trips_pass = [npuf, S.npass_updh, S.npass_updq, S.npass_inv, S.npass_bwd if all_half else 0, 0 if all_half else S.npass_bwd]
     children = lambda h: sorted([g for g in hdrs if parent[g] == h], key=lambda g: min(loops[g]))
     top = [h for h in hdrs if parent[h] is None]
-    ipm = max(hdrs, key=lambda h: (feat[h]["setprio"] > 0 or any(feat[g]["setprio"] for g in hdrs if loops[g] <= loops[h]), -len(loops[h])))
     # the interior-point loop = the smallest loop that holds the s_setprio of the priority balancing AND the pass loops
     cands = [h for h in hdrs if sum(feat[g]["setprio"] for g in hdrs if loops[g] <= loops[h]) > 0 and sum(feat[g]["gload"] > 0 and feat[g]["ds"] >= 5 for g in hdrs if loops[g] < loops[h]) >= 3]
     ipm = min(cands, key=lambda h: len(loops[h]))
@@ -305,8 +299,7 @@ def main():
             what = "topology work that runs only when a line is out in the wavefront: modelled at P(line out in the wavefront) x 3 trips"
         assign(h, f, what)
         for c in children(h):
-            inside_second = h == ipm
-            walk(c, f * ((T - 1) / T if h == ipm and c in passes + zero[:0] else 1.0))
+            walk(c, f * ((T - 1) / T if h == ipm and c in passes else 1.0))          # the Newton step runs T - 1 times: the loop's last trip only tests convergence
     # copy loops at the top: once per wavefront, trip counts from the table sizes (negligible either way)
     for h in top:
         if h != W: assign(h, 8.0, "copy of the case tables into LDS")
@@ -323,8 +316,6 @@ def budget(D, T):
     D["freq_loop"].clear()
     for h in [h for h in loops if parent[h] is None and h != D["W"]]:
         D["freq_loop"][h] = 8.0; D["notes"][h] = "copy of the case tables into LDS"
-    # walk() needs T in its closure: rebuild through main's helper
-    globals()["_T"] = T
     D["walk"](D["W"], 1.0)
     fb = {}
     innermost = {}
