@@ -4,7 +4,7 @@
 # ablate/librelmc_hostasan.so with the sanitizer runtime preloaded into python.  Leak checking is off (python itself never frees at exit).
 #   bash scripts/host_asan.sh [log]
 R=$(cd "$(dirname "$0")/.." && pwd); cd $R
-LOG=${1:-profiles/r5_final/host_asan.log}
+LOG=${1:-profiles/r6_final/host_asan.log}
 make -C powersystemsreliabilityassessment_amd/csrc host-asan > /tmp/host_asan_build.log 2>&1 || { tail -20 /tmp/host_asan_build.log; exit 1; }
 RT=$(/opt/rocm/bin/hipcc --offload-arch=gfx950 -print-file-name=libclang_rt.asan-x86_64.so)
 export RELMC_LIB_PATH=$R/powersystemsreliabilityassessment_amd/csrc/ablate/librelmc_hostasan.so
@@ -13,7 +13,7 @@ export UBSAN_OPTIONS=print_stacktrace=1:halt_on_error=1
 {
   echo "# host code of librelmc under -fsanitize=address,undefined (device code not instrumented), $(date -u +%FT%TZ)"
   echo "# library $RELMC_LIB_PATH, runtime $RT"
-  LD_PRELOAD=$RT python -m pytest tests/test_schedule.py tests/test_host.py tests/test_matpower.py tests/test_c_abi.py -q -m "not gpu" -p no:cacheprovider 2>&1
+  LD_PRELOAD=$RT python -m pytest tests/test_schedule.py tests/test_host.py tests/test_matpower.py tests/test_c_abi.py tests/test_screen.py -q -m "not gpu" -p no:cacheprovider 2>&1
   echo "pytest rc $?"
   # the order tuner on both shipped cases (thousands of schedules built and costed) and the symbolic models of the why-not page
   echo "## order tuner, RTS-24 (3000 evaluations) and RTS-96 (600)"
