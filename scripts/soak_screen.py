@@ -1,0 +1,27 @@
+"""Soak of the zero-curtailment pre-screen against the unscreened routes (round 6):  python scripts/soak_screen.py [n24] [n96]
+RTS-24: n24 samples (default 1e10) behind the pre-screen against the same samples through the state database (distinct states solved once, unscreened);
+RTS-96: n96 samples (default 1e9) behind the pre-screen against every sample solved.  Integers of relmc_acc must be identical but the iteration sum."""
+import os, sys, time
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import numpy as np
+from powersystemsreliabilityassessment_amd import api, case24, case96, _abi, dist
+n24 = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**10
+n96 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10**9
+def split(a):
+    i, d = a.to_arrays(); return np.concatenate([i[:5], i[6:-1]]), int(i[5]), int(i[-1]), d
+eng = api.Engine(case24.rts24())
+t = time.time(); tot = _abi.Acc(); ch = 2 * 10**9
+for lo in range(0, n24, ch):
+    tot = dist.merge(tot, eng.nsq_accumulate(3, lo, min(ch, n24 - lo), api.mpoption(screen=1)))
+t1 = time.time() - t
+t = time.time(); db = eng.nsqMain(beta_limit=0.0, max_iterations=n24, samples_per_batch=50_000_000, seed=3, distinct_states="database"); t2 = time.time() - t
+a, ita, sa, da = split(tot); b, itb, sb, dbl = split(db.acc)
+print(f"RTS-24, {n24:.3g} samples: pre-screen {t1:.1f} s ({n24 / t1 / 1e6:.0f} M/s), {sa / n24:.4f} certified, second attempts {eng.retry_stats()}; state database (unscreened) {t2:.1f} s, {db.database_row_count} rows")
+print("   integers identical:", bool(np.array_equal(a, b)), " sums max rel diff %.2e" % np.max(np.abs(da - dbl) / np.maximum(np.abs(dbl), 1e-300)), " EDNS %.5f MW, beta %.5f %%, non-converged %d" % (tot.sum_dns / tot.n, 100 * dist.indices_from_acc(tot, 24, 71)["beta"], tot.n_nonconverged))
+eng.close()
+e96 = api.Engine(case96.rts96())
+t = time.time(); s1 = e96.nsq_accumulate(3, 0, n96, api.mpoption(screen=1)); t1 = time.time() - t
+t = time.time(); s0 = e96.nsq_accumulate(3, 0, n96, api.mpoption()); t2 = time.time() - t
+a, ita, sa, da = split(s1); b, itb, sb, dbl = split(s0)
+print(f"RTS-96, {n96:.3g} samples: pre-screen {t1:.1f} s ({n96 / t1 / 1e6:.0f} M/s), {sa / n96:.4f} certified; every sample solved {t2:.1f} s; second attempts {e96.retry_stats()}, dense {e96.retry_dense_stats()}")
+print("   integers identical:", bool(np.array_equal(a, b)), " sums max rel diff %.2e" % np.max(np.abs(da - dbl) / np.maximum(np.abs(dbl), 1e-300)), " non-converged screened / unscreened %d / %d" % (s1.n_nonconverged, s0.n_nonconverged))
