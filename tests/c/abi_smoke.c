@@ -96,6 +96,56 @@ static int same_seq(const relmc_seq_result* a, const relmc_seq_result* b, const 
     }
     return 1;
 }
+/* ---- relmc_nsq_run at the reference's checkpoint spacing (nsqMain.m:60: 100 samples) as TWO ranks of this process: the multi-rank loop walks stretches of
+ * checkpoints, ONE vector all-reduce per stretch through the rendezvous above, and stops at the one-rank run's checkpoint with its history.  Twice: with and
+ * without the vector transport (the per-130-doubles path through the relmc_acc callback), every sample solved and behind the pre-screen. */
+typedef struct { relmc_ctx* ctx; relmc_nsq_opts o; relmc_nsq_result r; double* beta; int rc; } nsq_rank_t;
+static void* nsq_rank_main(void* arg)
+{
+    nsq_rank_t* t = (nsq_rank_t*)arg;
+    t->o.beta_history = t->beta;
+    t->rc = relmc_nsq_run(t->ctx, &t->o, &t->r);
+    return NULL;
+}
+static int run_nsq_stretches(relmc_ctx* ctx, const relmc_case_desc* d, const int32_t* order)
+{
+    enum { CAP = 12000 };
+    static double b_plain[CAP], b_r0[CAP], b_r1[CAP];
+    relmc_ctx* c1 = NULL;
+    if (relmc_ctx_create(0, &c1) != RELMC_OK || relmc_case_order_hint(c1, order, d->nb) != RELMC_OK || relmc_case_load(c1, d) != RELMC_OK) return 1;
+    for (int variant = 0; variant < 3; ++variant) {            /* 0: vector transport; 1: relmc_acc callback only; 2: vector transport + pre-screen */
+        relmc_nsq_opts o; relmc_nsq_opts_default(&o);
+        o.beta_limit = 0.02; o.max_samples = 1100000; o.batch = 100; o.seed = 6; o.history_cap = CAP; o.solver.screen = variant == 2;
+        relmc_nsq_result plain;
+        o.beta_history = b_plain;
+        if (relmc_nsq_run(ctx, &o, &plain) != RELMC_OK || !plain.converged || plain.checkpoints < 300 || plain.checkpoints >= CAP) return 2;
+        static pair_t pair; memset(&pair, 0, sizeof(pair));
+        pthread_mutex_init(&pair.m, NULL); pthread_cond_init(&pair.cv, NULL);
+        if (relmc_comm_set_host_allreduce(ctx, 2, 0, pair_allreduce, &pair) != RELMC_OK || relmc_comm_set_host_allreduce(c1, 2, 1, pair_allreduce, &pair) != RELMC_OK) return 3;
+        if (variant != 1 && (relmc_comm_set_host_allreduce_f64(ctx, pair_allreduce_f64, &pair) != RELMC_OK || relmc_comm_set_host_allreduce_f64(c1, pair_allreduce_f64, &pair) != RELMC_OK)) return 3;
+        nsq_rank_t t0 = {ctx, o, plain, b_r0, -1}, t1 = {c1, o, plain, b_r1, -1};
+        pthread_t th;
+        if (pthread_create(&th, NULL, nsq_rank_main, &t1) != 0) return 4;
+        nsq_rank_main(&t0);
+        pthread_join(th, NULL);
+        if (t0.rc != RELMC_OK || t1.rc != RELMC_OK) { fprintf(stderr, "nsq two ranks: %s | %s\n", relmc_last_error(ctx), relmc_last_error(c1)); return 5; }
+        if (getenv("RELMC_SMOKE_VERBOSE")) fprintf(stderr, "nsq stretches variant %d: %lld checkpoints, %d vector + %d relmc_acc collectives\n", variant, (long long)plain.checkpoints, pair.vcalls, pair.calls);
+        if (t0.r.checkpoints != plain.checkpoints || t1.r.checkpoints != plain.checkpoints || t0.r.acc.n != plain.acc.n || t0.r.acc.n_fail != plain.acc.n_fail ||
+            t0.r.acc.n_screened != plain.acc.n_screened || memcmp(t0.r.acc.comp_fail, plain.acc.comp_fail, sizeof(plain.acc.comp_fail)) != 0 ||
+            memcmp(&t0.r.acc, &t1.r.acc, sizeof(relmc_acc)) != 0) return 6;
+        for (int64_t k = 0; k < plain.checkpoints; ++k) {
+            const double e = (b_r0[k] - b_plain[k]) / b_plain[k];
+            if (e > 1e-10 || e < -1e-10 || b_r0[k] != b_r1[k]) return 7;
+        }
+        /* a stretch is one collective (+ one for the cut): a handful for the whole run, not one per checkpoint */
+        if (variant != 1 ? (pair.vcalls < 2 || pair.vcalls > 16 || pair.calls != 0) : (pair.vcalls != 0 || pair.calls < 2)) return 8;
+        if (variant == 2 && !(plain.acc.n_screened > plain.acc.n / 2)) return 9;
+        relmc_comm_destroy(ctx); relmc_comm_destroy(c1);
+        pthread_mutex_destroy(&pair.m); pthread_cond_destroy(&pair.cv);
+    }
+    relmc_ctx_destroy(c1);
+    return 0;
+}
 static int run_seq(relmc_ctx* ctx, const relmc_case_desc* d, const int32_t* order, int hpy, const double* mttf, const double* mttr, const double* lf)
 {
     enum { MAXY = 600 };
@@ -202,6 +252,7 @@ int main(int argc, char** argv)
     /* the multi-rank loop itself (relmc_nsq_run with R > 1: contiguous split of every batch, one all-reduce per batch) on this one GPU:
      * a host collective for "2 ranks" whose transport is this process evaluating the OTHER rank's slice on a second context */
     if (run_two_ranks(&d, order, &no, &r_plain) != 0) return 21;
+    { const int rs = run_nsq_stretches(ctx, &d, order); if (rs != 0) { fprintf(stderr, "relmc_nsq_run stretches over two ranks: check %d failed\n", rs); return 25; } }
     { const int rs = run_seq(ctx, &d, order, hpy[0], mttf, mttr, lf); if (rs != 0) { fprintf(stderr, "relmc_seq_run check %d failed\n", rs); return 24; } }
     printf("%lld %lld %.9f %lld %s\n", (long long)acc.n, (long long)acc.n_fail, acc.sum_dns, (long long)nd, relmc_version());
     relmc_ctx_destroy(ctx);
