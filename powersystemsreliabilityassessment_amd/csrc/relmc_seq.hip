@@ -21,7 +21,7 @@ void seq_free(relmc_ctx* ctx)
 }
 
 namespace {
-// chronology of years [first_year, first_year + n_years) into freshly zeroed device masks
+// chronology of years [first_year, first_year + n_years) into device masks (every word written)
 // *dmasks_out == nullptr on entry: a buffer is allocated for the caller (who frees it); otherwise the masks go into the caller's buffer
 int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, uint32_t** dmasks_out)
 {
@@ -29,9 +29,16 @@ int seq_sample(relmc_ctx* ctx, uint64_t seed, uint64_t first_year, int n_years, 
     const bool own = *dmasks_out == nullptr;
     uint32_t* dm = *dmasks_out;
     if (own) HIP_TRY(ctx, hipMalloc(&dm, words * sizeof(uint32_t)));
-    if (hipMemsetAsync(dm, 0, words * sizeof(uint32_t), ctx->stream) != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: memset failed"); }
-    const int64_t nthr = (int64_t)n_years * ctx->hseq.ncomp;
-    hipLaunchKernelGGL(relmc_seq_sampling_kernel, dim3((unsigned)((nthr + 255) / 256)), dim3(256), 0, ctx->stream, ctx->dseq, seed, first_year, n_years, dm);
+    // segments of at most ~48 KB of masks in LDS, and at least ~2 workgroups per CU over the launch (a segment's chains are walked from hour 0: cheap)
+    const int hpy = ctx->hseq.hpy, mw = ctx->hseq.mw, cap = (48 * 1024) / (4 * mw) - 64;
+    int nseg = (hpy + cap - 1) / cap;
+    while ((int64_t)n_years * nseg < 2 * (int64_t)ctx->num_cu && nseg < 16 && hpy / (nseg + 1) >= 256) ++nseg;
+    const int seg_len = (hpy + nseg - 1) / nseg;
+    nseg = (hpy + seg_len - 1) / seg_len;
+    int sl = seg_len;                                            // LDS row stride = 64 / mw (mod 64): conflict-free word-major rows
+    while (sl % 64 != (64 / mw) % 64) ++sl;
+    hipLaunchKernelGGL(relmc_seq_sampling_kernel, dim3((unsigned)((int64_t)n_years * nseg)), dim3(256), (size_t)sl * mw * sizeof(uint32_t), ctx->stream,
+                       ctx->dseq, seed, first_year, nseg, seg_len, sl, dm);
     if (hipGetLastError() != hipSuccess) { if (own) (void)hipFree(dm); return fail(ctx, RELMC_ERR_HIP, "seq: sampling launch failed"); }
     *dmasks_out = dm;
     return RELMC_OK;

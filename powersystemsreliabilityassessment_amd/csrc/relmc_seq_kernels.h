@@ -5,38 +5,61 @@
 
 namespace relmc {
 
-// seq_mcsampling.m:35-76, one thread per (year, component): alternate TTF = round(-MTTF ln U) and
-// TTR = ceil(-MTTR ln U), every year starts all-up (seqMain.m:91 calls it with num_years = 1).  U of event e of
-// component k in global year y = (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key=seed)[e & 3] + 0.5) / 2^32.
-// Down hours are OR-ed into masks[year][hour][mw x u32] (bit k), which must be zero on entry.
+// seq_mcsampling.m:35-76: alternate TTF = round(-MTTF ln U) and TTR = ceil(-MTTR ln U), every year starts all-up (seqMain.m:91 calls it
+// with num_years = 1).  U of event e of component k in global year y = (philox(ctr=(y_lo, y_hi, k | 0x80000000, e >> 2), key=seed)[e & 3] + 0.5) / 2^32.
+// One workgroup per (year, segment of seg_len hours).  A lane walks one component's chain from hour 0 (tens of events; components dealt
+// round-robin to the four wavefronts, so each has its share of the frequently failing units); a down interval that reaches into the segment
+// is filled by the whole wavefront, 64 hours per step, into the segment's masks in LDS (word-major, row stride `sl` = 64 / mw mod 64 so that
+// both the fill and the copy-out are conflict-free).  The finished segment leaves as one coalesced copy to masks[year][hour][mw x u32]
+// (bit k) -- every word written: no zero-fill, no global atomics.
 __global__ void __launch_bounds__(256) relmc_seq_sampling_kernel(const SeqCase* __restrict__ Q, uint64_t seed, uint64_t first_year,
-                                                                 int32_t n_years, uint32_t* __restrict__ masks)
+                                                                 int32_t nseg, int32_t seg_len, int32_t sl, uint32_t* __restrict__ masks)
 {
+    extern __shared__ uint32_t seg[];
     const int ncomp = Q->ncomp, hpy = Q->hpy, mw = Q->mw;
-    const int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
-    if (t >= (int64_t)n_years * ncomp) return;
-    const int y = (int)(t / ncomp), k = (int)(t - (int64_t)y * ncomp);
+    const int y = (int)(blockIdx.x / (unsigned)nseg), sg = (int)(blockIdx.x - (unsigned)y * (unsigned)nseg);
+    const int lo = sg * seg_len, hi = lo + seg_len < hpy ? lo + seg_len : hpy;
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    for (int q = threadIdx.x; q < sl * mw; q += 256) seg[q] = 0u;
+    __syncthreads();
     const uint64_t gy = first_year + (uint64_t)y;
-    const double mttf = Q->mttf[k], mttr = Q->mttr[k];
-    long long current = 0;
-    bool up = true;
-    uint32_t w[4];
-    for (int ev = 0; current < hpy; ++ev) {
-        if ((ev & 3) == 0)
-            philox4x32_10((uint32_t)gy, (uint32_t)(gy >> 32), (uint32_t)k | 0x80000000u, (uint32_t)(ev >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), w);
-        const double u = ((double)w[ev & 3] + 0.5) * 2.3283064365386963e-10;   // (0, 1)
-        if (up) {
-            current += (long long)__builtin_floor(-mttf * log(u) + 0.5);        // round(), seq_mcsampling.m:53
-        } else {
-            const long long dur = (long long)__builtin_ceil(-mttr * log(u));    // ceil(), >= 1 h, seq_mcsampling.m:60
-            long long end = current + dur - 1;
-            if (end > hpy - 1) end = hpy - 1;
-            for (long long h = current; h <= end; ++h)
-                atomicOr(&masks[((size_t)y * hpy + (size_t)h) * mw + (k >> 5)], 1u << (k & 31));
-            current += dur;
+    for (int k0 = 0; k0 < ncomp; k0 += 256) {
+        const int k = k0 + lane * 4 + wv;
+        const bool mine = k < ncomp;
+        const double mttf = mine ? Q->mttf[k] : 1.0, mttr = mine ? Q->mttr[k] : 1.0;
+        long long current = mine ? 0 : (long long)hi;
+        bool up = true;
+        uint32_t w[4];
+        for (int ev = 0; ; ++ev) {
+            const bool act = current < hi;                                           // events from `hi` on belong to later segments
+            if (!__any(act)) break;
+            if ((ev & 3) == 0)
+                philox4x32_10((uint32_t)gy, (uint32_t)(gy >> 32), (uint32_t)k | 0x80000000u, (uint32_t)(ev >> 2), (uint32_t)seed, (uint32_t)(seed >> 32), w);
+            const double l = log(((double)w[ev & 3] + 0.5) * 2.3283064365386963e-10);   // U in (0, 1)
+            int fb = 0, fe = 0;
+            if (act) {
+                if (up) current += (long long)__builtin_floor(-mttf * l + 0.5);     // round(), seq_mcsampling.m:53
+                else {
+                    const long long dur = (long long)__builtin_ceil(-mttr * l);      // ceil(), >= 1 h, seq_mcsampling.m:60
+                    const long long b = current > lo ? current : lo, e = current + dur < hi ? current + dur : hi;   // e: one past the last down hour
+                    if (e > b) { fb = (int)(b - lo); fe = (int)(e - lo); }
+                    current += dur;
+                }
+            }
+            up = !up;
+            for (uint64_t pend = __ballot(fe > fb); pend; pend &= pend - 1) {
+                const int src = __builtin_ctzll(pend);
+                const int sb = __builtin_amdgcn_readlane(fb, src), se = __builtin_amdgcn_readlane(fe, src), sk = k0 + src * 4 + wv;
+                uint32_t* const row = seg + (sk >> 5) * sl;
+                const uint32_t bit = 1u << (sk & 31);
+                for (int h = sb + lane; h < se; h += 64) atomicOr(&row[h], bit);     // the other wavefronts write other bits of the same words
+            }
         }
-        up = !up;
     }
+    __syncthreads();
+    uint32_t* const out = masks + ((size_t)y * hpy + (size_t)lo) * mw;
+    const int nw = (hi - lo) * mw;
+    for (int q = threadIdx.x; q < nw; q += 256) out[q] = seg[(q % mw) * sl + q / mw];
 }
 
 // masks -> uint8 states [years][hours][ncomp] (the materialised seq_mcsampling output)
