@@ -175,6 +175,23 @@ def test_gpu_chronology_bit_exact(seqeng, oracle, rel):
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("hpy,years", [(24, 2), (257, 5), (1000, 40), (8736, 1), (8736, 200), (20000, 3), (65535, 2)])
+def test_gpu_chronology_segments(engine, oracle, rel, hpy, years):
+    """The chronology kernel cuts a year into hour segments by the year's length and the number of years in the call (one workgroup per
+    segment, its masks in LDS): other lengths and counts than the reference's 8736 x 1, and failure-prone components (MTTF of a few hours to a
+    few days: hundreds of intervals per year, many of them across segment borders), against the oracle's chronology."""
+    fast = rel.copy()
+    fast[::3, 0] = np.linspace(3.0, 90.0, len(fast[::3]))          # every third component fails every few hours to days
+    fast[1::3, 1] = np.linspace(1.0, 400.0, len(fast[1::3]))       # ... and repairs of up to weeks
+    for data in (rel, fast):
+        se = seq.SeqEngine(engine, reliability_data=data, hours_per_year=hpy, load_scale_factors=np.ones(hpy))
+        got = se.seq_mcsampling(num_years=years, seed=4, first_year=2**33 + 7)
+        ref = oracle.seq_mcsampling(data, hpy, 4, 2**33 + 7, years)
+        np.testing.assert_array_equal(got.T, ref)
+    seq.SeqEngine(engine)                                          # the module's engine goes on with the reference's chronology
+
+
+@pytest.mark.gpu
 def test_gpu_scaled_hours_parity(seqeng, oracle, hours_fixture):
     from powersystemsreliabilityassessment_amd import api
     for name, pol in (("emulate", _abi.RELMC_REFERENCE_EMULATE), ("physical", _abi.RELMC_PHYSICAL)):
