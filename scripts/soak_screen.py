@@ -1,12 +1,15 @@
-"""Soak of the zero-curtailment pre-screen against the unscreened routes (round 6):  python scripts/soak_screen.py [n24] [n96]
+"""Soak of the zero-curtailment pre-screen against the unscreened routes (round 6):  python scripts/soak_screen.py [n24] [n96] [years]
 RTS-24: n24 samples (default 1e10) behind the pre-screen against the same samples through the state database (distinct states solved once, unscreened);
-RTS-96: n96 samples (default 1e9) behind the pre-screen against every sample solved.  Integers of relmc_acc must be identical but the iteration sum."""
+RTS-96: n96 samples (default 1e9) behind the pre-screen against every sample solved.  Integers of relmc_acc must be identical but the iteration sum.
+Sequential track: `years` simulated years (default 50 000, in calls of 1 000) behind the pre-screen against every contingency hour solved: annual
+(ens, dlc, nlc, contingency hours) identical year by year."""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np
-from powersystemsreliabilityassessment_amd import api, case24, case96, _abi, dist
+from powersystemsreliabilityassessment_amd import api, case24, case96, _abi, dist, seq
 n24 = int(float(sys.argv[1])) if len(sys.argv) > 1 else 10**10
 n96 = int(float(sys.argv[2])) if len(sys.argv) > 2 else 10**9
+nyr = int(float(sys.argv[3])) if len(sys.argv) > 3 else 50000
 def split(a):
     i, d = a.to_arrays(); return np.concatenate([i[:5], i[6:-1]]), int(i[5]), int(i[-1]), d
 eng = api.Engine(case24.rts24())
@@ -18,6 +21,19 @@ t = time.time(); db = eng.nsqMain(beta_limit=0.0, max_iterations=n24, samples_pe
 a, ita, sa, da = split(tot); b, itb, sb, dbl = split(db.acc)
 print(f"RTS-24, {n24:.3g} samples: pre-screen {t1:.1f} s ({n24 / t1 / 1e6:.0f} M/s), {sa / n24:.4f} certified, second attempts {eng.retry_stats()}; state database (unscreened) {t2:.1f} s, {db.database_row_count} rows")
 print("   integers identical:", bool(np.array_equal(a, b)), " sums max rel diff %.2e" % np.max(np.abs(da - dbl) / np.maximum(np.abs(dbl), 1e-300)), " EDNS %.5f MW, beta %.5f %%, non-converged %d" % (tot.sum_dns / tot.n, 100 * dist.indices_from_acc(tot, 24, 71)["beta"], tot.n_nonconverged))
+se = seq.SeqEngine(eng)
+tt = [0.0, 0.0]; same = True; tot = [_abi.Acc(), _abi.Acc()]; eens = 0.0
+for lo in range(0, nyr, 1000):
+    res = []
+    for w, so in enumerate((api.mpoption(), api.mpoption(screen=1))):
+        t = time.time(); res.append(se.seq_years(3, lo, min(1000, nyr - lo), so)); tt[w] += time.time() - t
+        tot[w] = dist.merge(tot[w], res[-1][4])
+    same = same and all(np.array_equal(res[0][q], res[1][q]) for q in range(4))
+    eens += float(res[1][0].sum())
+a, ita, sa, da = split(tot[1]); b, itb, sb, dbl = split(tot[0])
+print(f"sequential RTS-24, {nyr} years ({tot[0].n} contingency hours): pre-screen {tt[1]:.2f} s ({nyr / tt[1]:.0f} years/s), {sa / tot[1].n:.4f} certified; every hour solved {tt[0]:.1f} s")
+print("   annual ens / dlc / nlc / contingency hours identical year by year:", bool(same), " integers identical:", bool(np.array_equal(a, b)),
+      " sums max rel diff %.2e" % np.max(np.abs(da - dbl) / np.maximum(np.abs(dbl), 1e-300)), " EENS %.1f MWh/yr" % (eens / nyr))
 eng.close()
 e96 = api.Engine(case96.rts96())
 t = time.time(); s1 = e96.nsq_accumulate(3, 0, n96, api.mpoption(screen=1)); t1 = time.time() - t
