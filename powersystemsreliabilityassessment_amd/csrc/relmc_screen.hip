@@ -81,12 +81,32 @@ DEVFI bool screen_certify(const ScreenTab& T, const uint32_t (&m)[OW], double sc
         const double F1 = flow(m1), F2 = flow(m2);
         x1 = (a22 * F1 - a12 * F2) / det; x2 = (a11 * F2 - a21 * F1) / det;
     }
-    for (int l = 0; l < nl; ++l) {
-        if (nlo >= 1 && (l == m1 || (nlo == 2 && l == m2))) continue;      // a line out carries nothing
-        double f = flow(l);
-        if (nlo >= 1) f = __builtin_fma(h1[l], x1, f);
-        if (nlo == 2) f = __builtin_fma(h2[l], x2, f);
-        if (!(__builtin_fabs(f) <= T.lim[l])) return false;
+    // the lines, eight at a time: a unit's byte is taken out of the list once per eight lines and its eight pairs are in flight together; per line the
+    // same subtractions in the same order as flow(l), so the decisions are flow(l)'s
+    constexpr int CH = 8;
+    const double2* const gp = reinterpret_cast<const double2*>(T.gpair);
+    for (int l0 = 0; l0 < nl; l0 += CH) {
+        double a[CH], b[CH];
+        int lj[CH];
+#pragma unroll
+        for (int j = 0; j < CH; ++j) { lj[j] = l0 + j < nl ? l0 + j : nl - 1; a[j] = T.f_min[lj[j]]; b[j] = T.f_rng[lj[j]]; }
+        for (int i = 0; i < nout; ++i) {
+            const int k = (int)(((i < 8 ? list0 >> (8 * i) : list1 >> (8 * (i - 8)))) & 0xffull);
+#pragma unroll
+            for (int j = 0; j < CH; ++j) { const double2 v = gp[(size_t)lj[j] * ng + k]; a[j] -= v.x; b[j] -= v.y; }
+        }
+        bool over = false;
+#pragma unroll
+        for (int j = 0; j < CH; ++j) {
+            const int l = l0 + j;
+            if (l < nl && !(nlo >= 1 && (l == m1 || (nlo == 2 && l == m2)))) {      // a line out carries nothing
+                double f = __builtin_fma(t, b[j], a[j]) - scale * T.f_load[l];
+                if (nlo >= 1) f = __builtin_fma(h1[l], x1, f);
+                if (nlo == 2) f = __builtin_fma(h2[l], x2, f);
+                over = over || !(__builtin_fabs(f) <= T.lim[l]);
+            }
+        }
+        if (over) return false;
     }
     return true;
 }
