@@ -645,6 +645,13 @@ def screened_rates(eng24, device, policy, seed, B, steps=3):
                    "statistics are those of the unscreened run (tests/test_screen.py); `value` above stays every-sample-solved"}
     accs, dt, kms = timed(lambda k: eng24.nsq_accumulate(seed, (1 << 41) + k * B, B, so), eng24)
     res["nsq24"] = line(accs, dt, kms, B, "scenarios/s", f"HL2 non-sequential MCS, IEEE RTS-24, {B} samples per step (BASELINE configs[1]) behind the pre-screen")
+    nd = []
+    accs, dt, kms = timed(lambda k: (lambda r: (nd.append(r[1]), r[0])[1])(eng24.nsq_accumulate_distinct(seed, (1 << 41) + k * B, B, so)), eng24)
+    res["nsq24_distinct"] = line(accs, dt, kms, B, "scenarios/s", f"the same {B} samples per step: pre-screen, then the reference's per-batch dedupe (nsqMain.m:220-229) of the uncovered samples "
+                                                                   "(relmc_nsq_accumulate_distinct): only their distinct states are solved")
+    res["nsq24_distinct"]["distinct_states_solved_per_step"] = sum(nd[-steps:]) / steps
+    del res["nsq24_distinct"]["mean_ipm_iterations_of_the_solved"]        # sum_iters counts a distinct state's iterations once per sample that shares it
+    res["nsq24_distinct"]["uncovered_samples_per_step"] = res["nsq24_distinct"].pop("solved_per_step")
     eng24.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100, seed=seed, mpopt=so)
     t1 = time.perf_counter()
     r = eng24.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100, seed=seed, mpopt=so)

@@ -105,10 +105,11 @@ typedef struct {
                                  reference's outputs for it are exactly (0, zeros) (mc_simulation.m:57-59, 65) and it is counted without being solved.
                                  Every output but the iteration statistics is the one of screen = 0 (of its converged solves: a unit the interior point
                                  would have left non-converged is counted with the proven optimum); relmc_acc.n_screened counts the skipped units.
-                                 Honoured by the fused pass (relmc_nsq_accumulate, relmc_nsq_run), by the new rows of the state database
-                                 (relmc_nsq_db_batch: a certified row carries 0 iterations) and by the sequential track's contingency hours at
-                                 their own load factor (relmc_seq_years, relmc_seq_run); relmc_mc_simulation and relmc_nsq_accumulate_distinct
-                                 solve every state they are handed. */
+                                 Honoured by the fused pass (relmc_nsq_accumulate, relmc_nsq_run), by the per-batch dedupe
+                                 (relmc_nsq_accumulate_distinct: only the uncovered samples are sorted, their distinct states solved), by the new
+                                 rows of the state database (relmc_nsq_db_batch: a certified row carries 0 iterations) and by the sequential
+                                 track's contingency hours at their own load factor (relmc_seq_years, relmc_seq_run); relmc_mc_simulation
+                                 solves every state it is handed. */
     int32_t reserved;         /* 0 */
 } relmc_solver_opts;
 
@@ -210,6 +211,7 @@ int32_t relmc_nsq_accumulate(relmc_ctx* ctx, uint64_t seed, uint64_t first_index
 /* HIP-event duration (ms) of the most recent fused / simulation kernel on the ctx stream */
 /* The same accumulators through the reference's dedupe (nsqMain.m:220-245): sample the range, sort the outage masks on
  * the device, evaluate each distinct state once weighted by its multiplicity.  *n_distinct_out (optional) = states solved.
+ * With opts->screen = 1 the pre-screen's certificate runs first and only the uncovered samples are sorted and solved.
  * relmc_last_kernel_ms then covers sampling + sort + evaluation. */
 int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t n,
                                       const relmc_solver_opts* opts, relmc_acc* acc_out, int64_t* n_distinct_out);

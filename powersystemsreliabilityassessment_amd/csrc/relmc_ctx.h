@@ -214,6 +214,7 @@ void screen_free(relmc_ctx* ctx);
 int screen_build(relmc_ctx* ctx, const relmc_case_desc* d);          // relmc_case_load: PTDF / LODF tables of the certificate
 // samples [first_index, first_index + m): masks of the uncovered ones in ctx->screen.keys (own position), their ascending positions in ctx->screen.idx
 int screen_prepass_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int64_t m, uint32_t* n_surv, double* ms);
+int screen_gather_keys(relmc_ctx* ctx, uint32_t n_surv, uint32_t* keys_out);               // the uncovered samples' masks of the last screen_prepass_nsq, packed in sample order
 int screen_prepass_rows(relmc_ctx* ctx, int64_t first, int64_t n, uint32_t* n_surv);      // new database rows: certified ones filled in, the others listed
 int screen_seq_compact(relmc_ctx* ctx, const uint32_t* masks, int n_years, uint16_t* hours, uint32_t* counts, uint32_t* ncont);
 constexpr int64_t kScreenChunk = (int64_t)1 << 22;                   // samples per pre-pass of the fused path (its buffers: 4 OW + 5 bytes per sample)

@@ -372,35 +372,52 @@ int32_t relmc_nsq_accumulate_distinct(relmc_ctx* ctx, uint64_t seed, uint64_t fi
     relmc_solver_opts o;
     if (opts) o = *opts; else relmc_solver_opts_default(&o);
     HIP_TRY(ctx, hipSetDevice(ctx->device));
-    const int64_t kMaxPerLaunch = (int64_t)1 << 27;      // 32-bit weighted counters per scenario row
+    // screen = 1 (relmc_screen.hip): the zero-curtailment certificate runs first, one thread per sample; only the masks it does not cover are sorted and
+    // run-length encoded, and only their distinct states are solved.  Certified samples add 1 to n and to n_screened and nothing else.
+    const bool screen = o.screen != 0 && ctx->screen.tab.valid != 0;
+    const int64_t kMaxPerLaunch = screen ? kScreenChunk : (int64_t)1 << 27;      // 32-bit weighted counters per scenario row; the pre-pass' buffers
     double ms_total = 0.0;
     int64_t distinct_total = 0;
     for (int64_t done = 0; done < n;) {
         const int64_t m = (n - done) < kMaxPerLaunch ? (n - done) : kMaxPerLaunch;
         const auto t0 = std::chrono::steady_clock::now();
         uint32_t nu = 0; uint32_t* pin = nullptr;
-        int rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &pin);
+        int64_t certified = 0;
+        int rc = RELMC_OK;
+        if (screen) {
+            uint32_t ns = 0;
+            rc = memo_alloc(ctx, m);                                 // before the masks go into ctx->mk: memo_prepare must not move it
+            if (rc == RELMC_OK) rc = screen_prepass_nsq(ctx, seed, first_index + (uint64_t)done, m, &ns, nullptr);
+            if (rc == RELMC_OK) rc = screen_gather_keys(ctx, ns, ctx->mk);
+            if (rc == RELMC_OK && ns > 0) rc = memo_prepare(ctx, seed, 0, (int64_t)ns, &nu, &pin, /*keys_ready=*/true);
+            certified = m - (int64_t)ns;
+        } else rc = memo_prepare(ctx, seed, first_index + (uint64_t)done, m, &nu, &pin);
         if (rc) return rc;
         const double prep_ms = std::chrono::duration<double, std::milli>(std::chrono::steady_clock::now() - t0).count();
-        EvalArgs a = make_args(o);
-        a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
-        int rows = 0;
-        rc = fail_arm(ctx, a, 0, true, a.n);
-        if (rc) return rc;
-        rc = launch_eval(ctx, 3, a, &rows);
-        if (rc) return rc;
-        rc = launch_finalize(ctx, rows);
-        if (rc) return rc;
         relmc_acc part;
-        HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
-        rc = finish_timing(ctx);
-        if (rc) return rc;
-        ms_total += ctx->last_kernel_ms + prep_ms;       // sampling + sort + run-length encoding (host-timed) + evaluation kernel
-        RetryOut ro;
-        rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total);
-        if (rc) return rc;
-        for (size_t r = 0; r < ro.rec.size(); ++r)
-            acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);
+        relmc_acc_zero(&part);
+        if (nu > 0) {
+            EvalArgs a = make_args(o);
+            a.n = (int64_t)nu; a.memo_keys = ctx->mk; a.memo_perm = pin; a.memo_start = ctx->mstart;
+            int rows = 0;
+            rc = fail_arm(ctx, a, 0, true, a.n);
+            if (rc) return rc;
+            rc = launch_eval(ctx, 3, a, &rows);
+            if (rc) return rc;
+            rc = launch_finalize(ctx, rows);
+            if (rc) return rc;
+            HIP_TRY(ctx, hipMemcpyAsync(&part, ctx->dacc, sizeof(part), hipMemcpyDeviceToHost, ctx->stream));
+            rc = finish_timing(ctx);
+            if (rc) return rc;
+            ms_total += ctx->last_kernel_ms;
+            RetryOut ro;
+            rc = fail_retry(ctx, o, a.fail_threshold, nullptr, ro, &ms_total);
+            if (rc) return rc;
+            for (size_t r = 0; r < ro.rec.size(); ++r)
+                acc_add_unit(&part, ro.rec[r], ro.dns[r], ro.meta[r], &ro.nodal[r * (size_t)ctx->nb], ctx->nb, ctx->ncomp, a.fail_threshold);
+        }
+        ms_total += prep_ms;                                     // (pre-screen +) sampling + sort + run-length encoding, host-timed; the evaluation kernel above
+        part.n += certified; part.n_screened += certified;
         relmc_acc_merge(acc_out, &part);
         distinct_total += nu;
         done += m;

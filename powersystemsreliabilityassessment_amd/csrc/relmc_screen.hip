@@ -154,6 +154,16 @@ __global__ void __launch_bounds__(256) relmc_screen_keys_kernel(const ScreenTab 
     }
 }
 
+// out[j][ow] = keys[idx[j]][ow]: the uncovered samples' masks packed in ascending sample order (the per-batch dedupe sorts them)
+__global__ void __launch_bounds__(256) relmc_screen_gather_keys_kernel(const uint32_t* __restrict__ keys, const uint32_t* __restrict__ idx, int64_t ns, int ow,
+                                                                       uint32_t* __restrict__ out)
+{
+    for (int64_t t = (int64_t)blockIdx.x * blockDim.x + threadIdx.x; t < ns * ow; t += (int64_t)gridDim.x * blockDim.x) {
+        const int64_t j = t / ow; const int q = (int)(t - j * ow);
+        out[t] = keys[(size_t)idx[j] * ow + q];
+    }
+}
+
 // uint8 states [n][ncomp] -> mask words [n][OW]
 __global__ void __launch_bounds__(256) relmc_screen_pack_kernel(const uint8_t* __restrict__ states, int64_t n, int ncomp, int ow, uint32_t* __restrict__ keys)
 {
@@ -418,6 +428,16 @@ int screen_prepass_nsq(relmc_ctx* ctx, uint64_t seed, uint64_t first_index, int6
     *n_surv = ctx->hstage->fail_cnt;
     float t = 0.f;
     if (ms && hipEventElapsedTime(&t, S.ev0, S.ev1) == hipSuccess) *ms += t;
+    return RELMC_OK;
+}
+
+int screen_gather_keys(relmc_ctx* ctx, uint32_t n_surv, uint32_t* keys_out)
+{
+    if (n_surv == 0) return RELMC_OK;
+    auto& S = ctx->screen;
+    const int ow = mask_words(ctx);
+    hipLaunchKernelGGL(relmc_screen_gather_keys_kernel, dim3((unsigned)grid256(ctx, (int64_t)n_surv * ow)), dim3(256), 0, ctx->stream, S.keys, S.idx, (int64_t)n_surv, ow, keys_out);
+    HIP_TRY(ctx, hipGetLastError());
     return RELMC_OK;
 }
 

@@ -195,6 +195,34 @@ def test_screened_accumulate_equals_unscreened_rts24_2e6(engine, policy, capsys)
 
 
 @pytest.mark.gpu
+def test_screened_per_batch_dedupe(engine, case96_, capsys):
+    """relmc_nsq_accumulate_distinct behind the pre-screen: the certificate first, then sort + run-length encoding of the uncovered samples only and one
+    solve per distinct state among them.  Integers = the fused pass' (screened and not), sums to their order, n_screened = the fused screened pass'."""
+    n = 1_000_000
+    for eng, m in ((engine, n), (api.Engine(case96_), 300_000)):
+        for policy in (api.REFERENCE_EMULATE, api.PHYSICAL):
+            plain = eng.nsq_accumulate(5, 77, m, api.mpoption(policy))
+            fused = eng.nsq_accumulate(5, 77, m, api.mpoption(policy, screen=1))
+            d0, nd0 = eng.nsq_accumulate_distinct(5, 77, m, api.mpoption(policy)); t0 = eng.last_kernel_ms()
+            d1, nd1 = eng.nsq_accumulate_distinct(5, 77, m, api.mpoption(policy, screen=1)); t1 = eng.last_kernel_ms()
+            for x in (fused, d0, d1):
+                assert np.array_equal(_split(x)[0], _split(plain)[0])
+                np.testing.assert_allclose(_split(x)[3], _split(plain)[3], rtol=1e-12, atol=0)
+            assert d1.n_screened == fused.n_screened > 0.9 * m and d0.n_screened == 0 and d1.n == m
+            assert 0 < nd1 < nd0 and nd1 < m - d1.n_screened + 1          # distinct states among the uncovered samples only
+        with capsys.disabled():
+            print(f"\n   per-batch dedupe behind the pre-screen, {eng.case.nb} buses, {m} samples: {nd0} -> {nd1} distinct states solved, {t0:.2f} -> {t1:.2f} ms", end="")
+        # one sample, an empty range, a range the certificate covers entirely
+        assert eng.nsq_accumulate_distinct(5, 3, 1, api.mpoption(screen=1))[0].n == 1 and eng.nsq_accumulate_distinct(5, 3, 0, api.mpoption(screen=1))[0].n == 0
+        if eng is not engine: eng.close()
+    # the sampling loop in this mode: the same stopping batch and indices as without the pre-screen
+    a = engine.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000, seed=2, distinct_states="batch")
+    b = engine.nsqMain(beta_limit=0.01, max_iterations=5_000_000, samples_per_batch=100_000, seed=2, distinct_states="batch", mpopt=api.mpoption(screen=1))
+    assert a.current_iteration == b.current_iteration and a.plc == b.plc and b.n_screened > 0.9 * b.current_iteration and a.n_screened == 0
+    np.testing.assert_allclose([b.accumulated_edns, b.current_beta], [a.accumulated_edns, a.current_beta], rtol=1e-12)
+
+
+@pytest.mark.gpu
 @pytest.mark.parametrize("policy", [api.REFERENCE_EMULATE, api.PHYSICAL])
 def test_screened_accumulate_equals_unscreened_rts96_3e5(case96_, policy, capsys):
     eng = api.Engine(case96_)
