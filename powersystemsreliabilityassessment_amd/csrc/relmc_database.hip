@@ -34,8 +34,17 @@ int memo_alloc(relmc_ctx* ctx, int64_t m, bool keep = false)
         return tmp_sort > tmp_scan ? tmp_sort : tmp_scan;
     };
     size_t tmp_need = tmp_for(m);
+    if (keep && m <= ctx->memo_cap && tmp_need > ctx->memo_tmp_bytes) {
+        // live keys, enough room for them, but rocprim asks for more scratch at this size than at the sizes the scratch was made for: the scratch
+        // holds no data, so it alone grows
+        if (ctx->mtmp) (void)hipFree(ctx->mtmp);
+        ctx->mtmp = nullptr; ctx->memo_tmp_bytes = 0;
+        HIP_TRY(ctx, hipMalloc(&ctx->mtmp, tmp_need));
+        ctx->memo_tmp_bytes = tmp_need;
+        return RELMC_OK;
+    }
     if (m > ctx->memo_cap || tmp_need > ctx->memo_tmp_bytes) {
-        if (keep) return fail(ctx, RELMC_ERR_INVALID, "state database: sort scratch too small for the miss list (internal)");
+        if (keep) return fail(ctx, RELMC_ERR_INVALID, "state database: the miss list is longer than the buffers it was gathered into (internal)");
         // rocprim switches algorithms with the size and its scratch need is not monotone across the switch points: size the scratch for
         // every smaller power-of-two fraction too, so that a later call on fewer items (the miss list of the same batch) never reallocates
         for (int64_t q = m >> 1; q >= 1; q >>= 1) { const size_t t = tmp_for(q); if (t > tmp_need) tmp_need = t; }
