@@ -28,5 +28,6 @@ bash scripts/screen_profile.sh r6f > $O/screen_profile.log 2>&1
 python tests/tools/golden_pin.py > $O/golden_pin.log 2>&1; echo "golden_pin rc $?"
 python tests/tools/numfail96_device.py > $O/numfail96_device.json 2> $O/numfail96_device.err; echo "numfail96 rc $?"
 python scripts/converged.py > $O/converged.log 2>&1
+make -C powersystemsreliabilityassessment_amd/csrc ablate/librelmc_pt.so > $O/make_pt.log 2>&1     # the phase-timing build of THIS source (a stale one lacks the newer symbols)
 python scripts/wave_tail.py > $O/wave_tail.log 2>&1
 head -c 300 $O/bench_default.json; echo; tail -3 $O/golden_pin.log
